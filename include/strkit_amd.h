@@ -1,0 +1,135 @@
+/*
+ * strkit_amd.h — C ABI of the MI355X (gfx950) repeat-count backend for STRkit's `strkit call`.
+ *
+ * This is the drop-in boundary for the per-read repeat-count hot path.  Reference call sites
+ * (paths relative to the STRkit tree) each entry point replaces:
+ *
+ *   strk_repeat_count        strkit_rust_ext.get_repeat_count(start, tr, fl, fr, motif, max_iters,
+ *                            local_search_range, step_size, use_shortcuts=False)
+ *                            — strkit/call/repeats.py:58-68 (import at repeats.py:7)
+ *   strk_count_loci[_device] the per-read loop of call_locus() that calls get_repeat_count once per
+ *                            read with the running start-count feedback
+ *                            — strkit/call/call_locus.py:1082,1125-1161; sharded over workers at
+ *                            strkit/call/call_sample.py:103-138,414
+ *   strk_score_table         one parasail semi-global alignment score per candidate copy number
+ *                            (the innermost operation; shape of strkit/call/repeats.py:33,40,124)
+ *   strk_ref_repeat_count    get_ref_repeat_count() incl. score_ref_boundaries()
+ *                            — strkit/call/repeats.py:23-43,73-192 (parasail sg_qe_scan_profile_sat)
+ *
+ * Conventions: plain pointers and sizes, caller-owned buffers, no allocation crosses the ABI
+ * except the opaque context.  Every function returns 0 on success or a negative STRK_E_* code;
+ * strk_last_error() returns a thread-local message.  A context is bound to one HIP device and
+ * must be used from one host thread at a time; it is created lazily inside a worker process
+ * (fork-safe: nothing touches HIP before strk_init).
+ *
+ * Sequences are 1 byte per base, ASCII over ACGT + IUPAC codes + 'X' (low-quality wildcard),
+ * case-insensitive (strkit/call/align_matrix.py:25-39).  Scoring is the reference's: match +2,
+ * mismatch -7, gap 5 per base (align_matrix.py:15-17).
+ */
+#ifndef STRKIT_AMD_H
+#define STRKIT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STRK_OK 0
+#define STRK_E_INVALID (-22) /* bad argument (EINVAL) */
+#define STRK_E_NOMEM (-12)   /* device or host allocation failed (ENOMEM) */
+#define STRK_E_DEVICE (-5)   /* HIP runtime / kernel failure (EIO) */
+#define STRK_E_NODEV (-19)   /* no usable gfx950 device (ENODEV) */
+#define STRK_E_EMPTY (-61)   /* nothing could be scored (Python's max() of an empty dict) */
+
+/* end-gap flags; s1 = the read window fl+tr+fr, s2 = the candidate fl+motif*i+fr */
+#define STRK_DB_BEG_FREE 1
+#define STRK_DB_END_FREE 2
+#define STRK_CAND_BEG_FREE 4
+#define STRK_CAND_END_FREE 8
+#define STRK_SG_ALL 15
+
+#define STRK_TIE_FIRST 0 /* Python max(): first maximal element (repeats.py:135,154) */
+#define STRK_TIE_LAST 1
+
+typedef struct strk_ctx strk_ctx;
+
+/* Search parameters = RepeatCountParams (strkit/call/repeat_count_params.py:9-14) + the two
+ * semantic switches the un-vendored Rust crate leaves open (see DESIGN.md "parity unpinned"). */
+typedef struct strk_params {
+    int32_t max_iters;          /* rc_params.max_iters                (params.py:45  -> 50) */
+    int32_t local_search_range; /* rc_params.initial_local_search_range (params.py:26 -> 3) */
+    int32_t step_size;          /* rc_params.initial_step_size          (params.py:27 -> 1) */
+    int32_t tie_rule;           /* STRK_TIE_FIRST */
+    int32_t end_flags;          /* STRK_SG_ALL */
+    int32_t feedback;           /* 1: start-count feedback across the reads of a locus
+                                   (call_locus.py:1129-1136,1161); 0: start = est_cn as given */
+    int32_t window;             /* half-width of the speculative score table per read; 0 = default */
+    int32_t reserved;
+} strk_params;
+
+/* CSR-packed batch of loci.  Read r owns seqs[seq_off[r] .. seq_off[r+1]) laid out fl|tr|fr;
+ * locus l owns reads read_off[l] .. read_off[l+1] (in caller order) and motif
+ * motifs[motif_off[l] .. motif_off[l+1]).  est_cn[r] is the caller's integer start estimate
+ * (get_est_copy_num(), call_locus.py:1129). */
+typedef struct strk_batch {
+    int32_t n_reads;
+    int32_t n_loci;
+    const uint8_t* seqs;
+    const int64_t* seq_off; /* [n_reads + 1] */
+    const int32_t* nfl;     /* [n_reads] */
+    const int32_t* ntr;
+    const int32_t* nfr;
+    const int32_t* est_cn;
+    const int32_t* read_off;  /* [n_loci + 1] */
+    const uint8_t* motifs;
+    const int32_t* motif_off; /* [n_loci + 1] */
+} strk_batch;
+
+/* Per-call statistics (all optional output). */
+typedef struct strk_stats {
+    int64_t dp_cells;      /* DP cell updates executed by the device kernels */
+    int32_t n_fallback;    /* reads scored by the generic (non-systolic) kernel */
+    int32_t n_miss_reads;  /* reads whose search left the speculative window (re-scored) */
+    int32_t n_miss_rounds; /* extra launch rounds needed to resolve them */
+    float kernel_ms;       /* HIP-event time of the device work of this call */
+    float dp_kernel_ms;    /* ... of the DP kernels alone */
+    int32_t n_dp_launches;
+    int32_t reserved;
+} strk_stats;
+
+int strk_init(int device, strk_ctx** out);
+void strk_destroy(strk_ctx* ctx);
+const char* strk_last_error(void);
+const char* strk_version(void);
+
+/* Scalar drop-in for strkit_rust_ext.get_repeat_count (repeats.py:58-68).  Return contract
+ * (repeats.py:55-56): ((out_cn, out_score), out_n_explored, out_cn - start_count). */
+int strk_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int32_t tr_len,
+                      const uint8_t* fl, int32_t fl_len, const uint8_t* fr, int32_t fr_len,
+                      const uint8_t* motif, int32_t motif_len, int32_t max_iters,
+                      int32_t local_search_range, int32_t step_size, int32_t* out_cn,
+                      int32_t* out_score, int32_t* out_n_explored);
+
+/* Batched per-locus path, HOST buffers in and out (all out_* are [n_reads] int32). */
+int strk_count_loci(strk_ctx* ctx, const strk_batch* batch, const strk_params* params,
+                    int32_t* out_cn, int32_t* out_score, int32_t* out_n_iters, int32_t* out_start,
+                    strk_stats* stats);
+
+/* Same, every pointer inside `batch` and every out_* pointer is DEVICE memory on ctx's device;
+ * work is enqueued on `stream` (a hipStream_t, NULL = default stream) and the call returns after
+ * the results are complete in out_* (it synchronises the stream once to check for window misses). */
+int strk_count_loci_device(strk_ctx* ctx, const strk_batch* batch, const strk_params* params,
+                           int32_t* out_cn, int32_t* out_score, int32_t* out_n_iters,
+                           int32_t* out_start, void* stream, strk_stats* stats);
+
+/* Parity primitive: scores[table_off[r] + k] = semi-global score of (fl + motif*(lo[r]+k) + fr)
+ * against (fl+tr+fr) for k < n[r].  HOST buffers.  table_off is [n_reads + 1]. */
+int strk_score_table(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, const int32_t* n,
+                     const int64_t* table_off, int32_t end_flags, int32_t force_generic,
+                     int32_t* scores, strk_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRKIT_AMD_H */

@@ -1,0 +1,52 @@
+"""Builds libstrkit_amd.so (HIP, gfx950 only) in-tree with hipcc.
+
+The shared library is the product's compute path; there is no CPU fallback.  hipcc cross-compiles
+gfx950 code objects without a GPU present, so this runs in the build container and on the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libstrkit_amd.so")
+SOURCES = ["strk_api.hip"]
+HEADERS = ["strk_kernels.h", "strk_scoring.h", "strk_search.h", os.path.join("..", "..", "include", "strkit_amd.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-Wall", "-Wextra", "-Wno-unused-parameter"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm); strkit_amd has no CPU fallback")
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the library if it is missing or older than its sources; returns its path."""
+    if not force and not stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = [_hipcc(), *HIPCC_FLAGS, "-o", tmp, *[os.path.join(CSRC, s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,139 @@
+"""ctypes binding of libstrkit_amd.so — the thin layer above the C ABI (include/strkit_amd.h).
+
+Fails loudly: if the HIP library cannot be loaded, or no gfx950 device can be initialised, every
+compute entry point raises.  There is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import _build
+
+STRK_SG_ALL = 15
+STRK_TIE_FIRST, STRK_TIE_LAST = 0, 1
+STRK_E_EMPTY = -61
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+
+class StrkParams(C.Structure):
+    _fields_ = [("max_iters", C.c_int32), ("local_search_range", C.c_int32), ("step_size", C.c_int32),
+                ("tie_rule", C.c_int32), ("end_flags", C.c_int32), ("feedback", C.c_int32), ("window", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class StrkBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_loci", C.c_int32), ("seqs", C.c_void_p), ("seq_off", C.c_void_p),
+                ("nfl", C.c_void_p), ("ntr", C.c_void_p), ("nfr", C.c_void_p), ("est_cn", C.c_void_p),
+                ("read_off", C.c_void_p), ("motifs", C.c_void_p), ("motif_off", C.c_void_p)]
+
+
+class StrkStats(C.Structure):
+    _fields_ = [("dp_cells", C.c_int64), ("n_fallback", C.c_int32), ("n_miss_reads", C.c_int32),
+                ("n_miss_rounds", C.c_int32), ("kernel_ms", C.c_float), ("dp_kernel_ms", C.c_float),
+                ("n_dp_launches", C.c_int32), ("reserved", C.c_int32)]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# Every symbol include/strkit_amd.h declares (tests check the .so exports exactly these).
+EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_repeat_count", "strk_count_loci",
+           "strk_count_loci_device", "strk_score_table")
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class StrkError(RuntimeError):
+    """Raised for any non-zero return of the C ABI (the worker's catch-all in the reference,
+    strkit/call/call_sample.py:159-166, turns it into 'locus skipped + logged')."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"strkit_amd error {code}: {msg}")
+        self.code = code
+
+
+def load(build: bool = True):
+    """dlopen the library (building it in-tree first if it is missing/stale and hipcc is present)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB_PATH
+        if build and _build.stale():
+            try:
+                _build.build()
+            except Exception as e:  # noqa: BLE001
+                if not os.path.exists(path):
+                    raise RuntimeError(f"libstrkit_amd.so is not built and could not be built: {e}") from e
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -m strkit_amd._build` (strkit_amd has no CPU fallback)")
+        L = C.CDLL(path)
+        L.strk_init.restype = C.c_int
+        L.strk_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.strk_destroy.restype = None
+        L.strk_destroy.argtypes = [C.c_void_p]
+        L.strk_last_error.restype = C.c_char_p
+        L.strk_version.restype = C.c_char_p
+        L.strk_repeat_count.restype = C.c_int
+        L.strk_repeat_count.argtypes = ([C.c_void_p, C.c_int32] + [C.c_char_p, C.c_int32] * 4 + [C.c_int32] * 3
+                                        + [_i32p] * 3)
+        L.strk_count_loci.restype = C.c_int
+        L.strk_count_loci.argtypes = [C.c_void_p, C.POINTER(StrkBatch), C.POINTER(StrkParams)] + [C.c_void_p] * 4 + [
+            C.POINTER(StrkStats)]
+        L.strk_count_loci_device.restype = C.c_int
+        L.strk_count_loci_device.argtypes = ([C.c_void_p, C.POINTER(StrkBatch), C.POINTER(StrkParams)]
+                                             + [C.c_void_p] * 4 + [C.c_void_p, C.POINTER(StrkStats)])
+        L.strk_score_table.restype = C.c_int
+        L.strk_score_table.argtypes = [C.c_void_p, C.POINTER(StrkBatch), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.c_int32, C.c_void_p, C.POINTER(StrkStats)]
+        _lib = L
+        return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise StrkError(rc, load().strk_last_error().decode("utf-8", "replace"))
+
+
+class Context:
+    """One HIP device context (strk_init / strk_destroy).  Created lazily per process and device:
+    the reference's workers are forked (strkit/call/call_sample.py:345-356), so nothing touches the
+    GPU at import time."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = C.c_void_p()
+        check(self._lib.strk_init(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+        self._pid = os.getpid()
+
+    def close(self) -> None:
+        if getattr(self, "handle", None) and self._pid == os.getpid():
+            self._lib.strk_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+_ctxs: dict[tuple[int, int], Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    if device is None:
+        device = int(os.environ.get("STRKIT_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    key = (os.getpid(), device)
+    ctx = _ctxs.get(key)
+    if ctx is None or ctx.handle is None:
+        ctx = _ctxs[key] = Context(device)
+    return ctx

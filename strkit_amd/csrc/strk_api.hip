@@ -1,0 +1,588 @@
+// strk_api.hip — host side of libstrkit_amd.so (C ABI declared in include/strkit_amd.h).
+//
+// One context = one HIP device.  A batched call enqueues, on the caller's stream:
+//   memset(counters) -> k_plan -> k_dp<class> x 13 -> k_dp_generic -> k_replay -> counters D2H
+// and synchronises once.  Only when a read's search left its speculative candidate window (rare;
+// strk_stats.n_miss_reads) does the host run extra rounds: re-score the wanted window on the
+// device, replay that locus on the host with the same search_replay() the device uses.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/strkit_amd.h"
+#include "strk_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? STRK_E_NOMEM : STRK_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(STRK_E_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct strk_ctx {
+    int device = 0;
+    // workspace
+    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, counters, scratch, state_i32, state_f64;
+    DevBuf win_lo2, win_n2, tab_off2, table2, items;
+    // staging for the host-buffer entry points
+    DevBuf in_seqs, in_seq_off, in_nfl, in_ntr, in_nfr, in_est, in_read_off, in_motifs, in_motif_off;
+    DevBuf out_cn, out_score, out_n, out_start;
+    int32_t* h_counters = nullptr;  // pinned: counters + cells + scratch_used
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_ints = 0;
+};
+
+namespace {
+
+using namespace strk;
+
+constexpr int kDefaultWindow = 8;
+constexpr size_t kScratchInts = (size_t)16 << 20;  // 64 MiB of int32 rows for the generic kernel
+// device layout of the `counters` buffer: int32[kCntTotal] | pad | u64 cells | u64 scratch_used
+constexpr size_t kCellsOff = 64 * sizeof(int32_t);
+constexpr size_t kCountersBytes = kCellsOff + 2 * sizeof(unsigned long long);
+
+template <int G, int CL>
+void launch_dp(const KArgs& a, int cls, int max_items, hipStream_t st) {
+    constexpr int gpb = DpLayout<G, CL>::GPB;
+    int grid = (max_items + gpb - 1) / gpb;
+    grid = std::max(1, std::min(grid, 256 * 8));
+    hipLaunchKernelGGL((k_dp<G, CL>), dim3(grid), dim3(256), 0, st, a, cls);
+}
+
+void launch_dp_class(const KArgs& a, int cls, int max_items, hipStream_t st) {
+    switch (cls) {
+    case 0: launch_dp<16, 8>(a, cls, max_items, st); break;
+    case 1: launch_dp<16, 12>(a, cls, max_items, st); break;
+    case 2: launch_dp<16, 16>(a, cls, max_items, st); break;
+    case 3: launch_dp<16, 20>(a, cls, max_items, st); break;
+    case 4: launch_dp<16, 24>(a, cls, max_items, st); break;
+    case 5: launch_dp<16, 28>(a, cls, max_items, st); break;
+    case 6: launch_dp<64, 8>(a, cls, max_items, st); break;
+    case 7: launch_dp<64, 12>(a, cls, max_items, st); break;
+    case 8: launch_dp<64, 16>(a, cls, max_items, st); break;
+    case 9: launch_dp<64, 20>(a, cls, max_items, st); break;
+    case 10: launch_dp<64, 24>(a, cls, max_items, st); break;
+    case 11: launch_dp<64, 28>(a, cls, max_items, st); break;
+    case 12: launch_dp<64, 32>(a, cls, max_items, st); break;
+    default: break;
+    }
+}
+static_assert(kNumClasses == 13, "launch_dp_class covers 13 classes");
+
+int check_params(const strk_params* p, strk_params* out) {
+    if (!p) return fail(STRK_E_INVALID, "params is NULL");
+    *out = *p;
+    if (out->window <= 0) out->window = kDefaultWindow;
+    if (2 * out->window + 1 > kTableMax) out->window = (kTableMax - 1) / 2;
+    if (out->local_search_range < 0 || out->step_size < 1)
+        return fail(STRK_E_INVALID, "local_search_range must be >= 0 and step_size >= 1");
+    if (out->tie_rule != STRK_TIE_FIRST && out->tie_rule != STRK_TIE_LAST) return fail(STRK_E_INVALID, "bad tie_rule");
+    if (out->end_flags < 0 || out->end_flags > 15) return fail(STRK_E_INVALID, "bad end_flags");
+    return 0;
+}
+
+// Common workspace sizing for a batch with n_reads / n_loci and at most n_items DP items.
+int ensure_workspace(strk_ctx* c, int n_reads, int n_loci, size_t table_ints, size_t n_items) {
+    const size_t nr = (size_t)std::max(n_reads, 1), nl = (size_t)std::max(n_loci, 1);
+    int rc;
+    if ((rc = c->read_locus.ensure(nr * 4))) return rc;
+    if ((rc = c->win_lo.ensure(nr * 4))) return rc;
+    if ((rc = c->win_n.ensure(nr * 4))) return rc;
+    if ((rc = c->tab_off.ensure(nr * 8))) return rc;
+    if ((rc = c->table.ensure(std::max<size_t>(table_ints, 1) * 4))) return rc;
+    if ((rc = c->cls_list.ensure((size_t)(kNumClasses + 1) * std::max<size_t>(n_items, 1) * 2 * 4))) return rc;
+    if ((rc = c->counters.ensure(kCountersBytes))) return rc;
+    if ((rc = c->state_i32.ensure(nl * 3 * 4))) return rc;
+    if ((rc = c->state_f64.ensure(nl * 8))) return rc;
+    if (!c->scratch.p) {
+        if ((rc = c->scratch.ensure(kScratchInts * 4))) return rc;
+        c->scratch_ints = kScratchInts;
+    }
+    return 0;
+}
+
+KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int table_stride, int list_stride) {
+    KArgs a;
+    memset(&a, 0, sizeof a);
+    a.seqs = b->seqs; a.seq_off = b->seq_off; a.nfl = b->nfl; a.ntr = b->ntr; a.nfr = b->nfr;
+    a.est_cn = b->est_cn; a.read_off = b->read_off; a.motifs = b->motifs; a.motif_off = b->motif_off;
+    a.n_reads = b->n_reads; a.n_loci = b->n_loci;
+    a.read_locus = c->read_locus.as<int32_t>();
+    a.win_lo = c->win_lo.as<int32_t>();
+    a.win_n = c->win_n.as<int32_t>();
+    a.tab_off = c->tab_off.as<int64_t>();
+    a.table = c->table.as<int32_t>();
+    a.cls_list = c->cls_list.as<int32_t>();
+    a.counters = c->counters.as<int32_t>();
+    a.cells = reinterpret_cast<unsigned long long*>(c->counters.as<char>() + kCellsOff);
+    a.scratch_used = a.cells + 1;
+    a.scratch = c->scratch.as<int32_t>();
+    a.scratch_cap = (long long)c->scratch_ints;
+    a.list_stride = list_stride;
+    a.end_flags = end_flags;
+    a.window = window;
+    a.table_stride = table_stride;
+    return a;
+}
+
+// plan (classification) + all DP kernels for the reads in `items` (NULL = all reads).
+void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_items, int n_items, int force_generic,
+                     hipStream_t st, bool time_dp) {
+    hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, a, mode, d_items, n_items, force_generic);
+    if (time_dp) (void)hipEventRecord(c->ev[1], st);
+    if (!force_generic)
+        for (int cls = 0; cls < kNumClasses; ++cls) launch_dp_class(a, cls, a.list_stride, st);
+    hipLaunchKernelGGL(k_dp_generic, dim3(256), dim3(256), 0, st, a);
+    if (time_dp) (void)hipEventRecord(c->ev[2], st);
+}
+
+int check_error_bits(int bits) {
+    if (bits & kErrBadInput) return fail(STRK_E_INVALID, "batch holds an empty motif or a negative length");
+    if (bits & kErrScratch) return fail(STRK_E_NOMEM, "generic-kernel scratch or item list exhausted (inputs too large for one call)");
+    if (bits & kErrEmpty) return fail(STRK_E_EMPTY, "max() arg is an empty sequence: no candidate size could be scored for some read");
+    return 0;
+}
+
+struct SeenVec {
+    std::vector<uint8_t> v;
+    bool test(int k) const { return v[(size_t)k] != 0; }
+    void set(int k) { v[(size_t)k] = 1; }
+};
+
+// Host-driven rounds for loci whose search left the speculative window.  Everything here works on
+// DEVICE batch pointers; host copies of the small metadata are fetched once.
+int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs a, ReplayArgs rp, hipStream_t st,
+                   strk_stats* stats) {
+    const int nr = b->n_reads, nl = b->n_loci;
+    std::vector<int32_t> read_off(nl + 1), est(nr), win_lo(nr), win_n(nr), next_read(nl), need_lo(nl), need_hi(nl);
+    std::vector<int64_t> tab_off(nr);
+    std::vector<double> frac(nl);
+    std::vector<int32_t> o_cn(nr), o_score(nr), o_n(nr), o_start(nr);
+    HIP_TRY(hipMemcpy(read_off.data(), b->read_off, (nl + 1) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(est.data(), b->est_cn, (size_t)nr * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(win_lo.data(), a.win_lo, (size_t)nr * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(win_n.data(), a.win_n, (size_t)nr * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tab_off.data(), a.tab_off, (size_t)nr * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(next_read.data(), rp.next_read, (size_t)nl * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(need_lo.data(), rp.need_lo, (size_t)nl * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(need_hi.data(), rp.need_hi, (size_t)nl * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(frac.data(), rp.frac, (size_t)nl * 8, hipMemcpyDeviceToHost));
+    const size_t main_ints = (size_t)nr * a.table_stride;
+    std::vector<int32_t> table(main_ints);
+    HIP_TRY(hipMemcpy(table.data(), a.table, main_ints * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(o_cn.data(), rp.out_cn, (size_t)nr * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(o_score.data(), rp.out_score, (size_t)nr * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(o_n.data(), rp.out_n, (size_t)nr * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(o_start.data(), rp.out_start, (size_t)nr * 4, hipMemcpyDeviceToHost));
+
+    std::vector<int> pending;  // loci
+    for (int l = 0; l < nl; ++l)
+        if (next_read[l] < read_off[l + 1]) pending.push_back(l);
+    // extended tables live on the host per read; (lo, scores)
+    std::vector<int32_t> ext_lo(nr, 0);
+    std::vector<std::vector<int32_t>> ext(nr);
+    int rounds = 0, miss_reads = 0;
+    int rc;
+    while (!pending.empty()) {
+        if (++rounds > 4096) return fail(STRK_E_DEVICE, "window-miss resolution did not converge");
+        // 1. windows wanted this round
+        std::vector<int32_t> items;
+        std::vector<int32_t> w_lo(nr, 0), w_n(nr, 0);
+        std::vector<int64_t> w_off(nr, 0);
+        size_t tab2 = 0, n_chunks = 0;
+        for (int l : pending) {
+            const int r = next_read[l];
+            int64_t cur_lo = ext[r].empty() ? win_lo[r] : ext_lo[r];
+            int64_t cur_hi = cur_lo + (ext[r].empty() ? win_n[r] : (int64_t)ext[r].size()) - 1;
+            int64_t lo2 = std::min<int64_t>(cur_lo, std::max<int64_t>(0, (int64_t)need_lo[l] - p.window));
+            int64_t hi2 = std::max<int64_t>(cur_hi, (int64_t)need_hi[l] + p.window);
+            if (hi2 - lo2 + 1 > (int64_t)1 << 20) return fail(STRK_E_INVALID, "candidate window grew past 2^20 sizes");
+            w_lo[r] = (int32_t)lo2;
+            w_n[r] = (int32_t)(hi2 - lo2 + 1);
+            w_off[r] = (int64_t)tab2;
+            tab2 += (size_t)w_n[r];
+            n_chunks += ((size_t)w_n[r] + kTableMax - 1) / kTableMax;
+            items.push_back(r);
+            ++miss_reads;
+        }
+        // 2. score them on the device
+        if ((rc = c->win_lo2.ensure((size_t)nr * 4))) return rc;
+        if ((rc = c->win_n2.ensure((size_t)nr * 4))) return rc;
+        if ((rc = c->tab_off2.ensure((size_t)nr * 8))) return rc;
+        if ((rc = c->table2.ensure(tab2 * 4))) return rc;
+        if ((rc = c->items.ensure(items.size() * 4))) return rc;
+        if ((rc = c->cls_list.ensure((size_t)(kNumClasses + 1) * n_chunks * 2 * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->win_lo2.p, w_lo.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->win_n2.p, w_n.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->tab_off2.p, w_off.data(), (size_t)nr * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->items.p, items.data(), items.size() * 4, hipMemcpyHostToDevice, st));
+        KArgs a2 = a;
+        a2.win_lo = c->win_lo2.as<int32_t>();
+        a2.win_n = c->win_n2.as<int32_t>();
+        a2.tab_off = c->tab_off2.as<int64_t>();
+        a2.table = c->table2.as<int32_t>();
+        a2.cls_list = c->cls_list.as<int32_t>();
+        a2.list_stride = (int32_t)n_chunks;
+        HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
+        enqueue_scoring(c, a2, 1, c->items.as<int32_t>(), (int)items.size(), 0, st, false);
+        HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
+        std::vector<int32_t> t2(tab2);
+        HIP_TRY(hipMemcpyAsync(t2.data(), c->table2.p, tab2 * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
+        if ((rc = check_error_bits(c->h_counters[kCntError] & ~kErrEmpty))) return rc;
+        if (stats) {
+            stats->n_fallback += c->h_counters[kCntClass0 + kGenericClass];
+            stats->dp_cells += (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
+        }
+        for (int r : items) {
+            ext_lo[r] = w_lo[r];
+            ext[r].assign(t2.begin() + w_off[r], t2.begin() + w_off[r] + w_n[r]);
+        }
+        // 3. replay the pending loci on the host until the next miss
+        std::vector<int> still;
+        for (int l : pending) {
+            int r = next_read[l];
+            double fr = frac[l];
+            bool missed = false;
+            for (; r < read_off[l + 1]; ++r) {
+                int start = est[r];
+                double fr_try = fr;
+                if (p.feedback) start = feedback_start(est[r], &fr_try);
+                const bool use_ext = !ext[r].empty();
+                const int32_t* sc = use_ext ? ext[r].data() : table.data() + tab_off[r];
+                const int32_t lo = use_ext ? ext_lo[r] : win_lo[r];
+                const int32_t n = use_ext ? (int32_t)ext[r].size() : win_n[r];
+                SeenVec seen;
+                seen.v.assign((size_t)std::max(n, 1), 0);
+                const SearchResult res = search_replay(start, p.step_size, p.local_search_range, p.max_iters,
+                                                       p.tie_rule == STRK_TIE_LAST, sc, lo, n, seen);
+                if (res.miss) {
+                    need_lo[l] = res.need_lo;
+                    need_hi[l] = res.need_hi;
+                    missed = true;
+                    break;
+                }
+                fr = fr_try;
+                o_start[r] = start;
+                o_n[r] = res.n_explored;
+                if (res.empty) {
+                    o_cn[r] = 0; o_score[r] = 0;
+                    c->h_counters[kCntError] |= kErrEmpty;
+                    continue;
+                }
+                o_cn[r] = res.cn;
+                o_score[r] = res.score;
+                if (p.feedback) feedback_update(&fr, res.cn, start);
+            }
+            next_read[l] = r;
+            frac[l] = fr;
+            if (missed) still.push_back(l);
+        }
+        pending.swap(still);
+    }
+    HIP_TRY(hipMemcpyAsync(rp.out_cn, o_cn.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rp.out_score, o_score.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rp.out_n, o_n.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rp.out_start, o_start.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (stats) {
+        stats->n_miss_reads = miss_reads;
+        stats->n_miss_rounds = rounds;
+    }
+    return check_error_bits(c->h_counters[kCntError]);
+}
+
+int count_device(strk_ctx* c, const strk_batch* b, const strk_params* params, int32_t* out_cn, int32_t* out_score,
+                 int32_t* out_n, int32_t* out_start, hipStream_t st, strk_stats* stats) {
+    strk_params p;
+    int rc;
+    if ((rc = check_params(params, &p))) return rc;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!b || b->n_reads < 0 || b->n_loci < 0) return fail(STRK_E_INVALID, "bad batch");
+    if (b->n_reads == 0 || b->n_loci == 0) return 0;
+    if (!out_cn || !out_score || !out_n || !out_start) return fail(STRK_E_INVALID, "output pointer is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    const int ts = 2 * p.window + 1;
+    if ((rc = ensure_workspace(c, b->n_reads, b->n_loci, (size_t)b->n_reads * ts, (size_t)b->n_reads))) return rc;
+    KArgs a = make_args(c, b, p.end_flags, p.window, ts, b->n_reads);
+    ReplayArgs rp;
+    rp.max_iters = p.max_iters; rp.lsr = p.local_search_range; rp.step = p.step_size;
+    rp.tie_last = p.tie_rule == STRK_TIE_LAST; rp.feedback = p.feedback;
+    rp.out_cn = out_cn; rp.out_score = out_score; rp.out_n = out_n; rp.out_start = out_start;
+    rp.next_read = c->state_i32.as<int32_t>();
+    rp.need_lo = rp.next_read + b->n_loci;
+    rp.need_hi = rp.need_lo + b->n_loci;
+    rp.frac = c->state_f64.as<double>();
+
+    HIP_TRY(hipEventRecord(c->ev[0], st));
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
+    enqueue_scoring(c, a, 0, nullptr, b->n_reads, 0, st, true);
+    hipLaunchKernelGGL(k_replay, dim3((b->n_loci + 63) / 64), dim3(64), 0, st, a, rp);
+    HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(c->ev[3], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) stats->kernel_ms = ms;
+        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) stats->dp_kernel_ms = ms;
+        stats->n_dp_launches = kNumClasses + 1;
+        stats->n_fallback = c->h_counters[kCntClass0 + kGenericClass];
+        stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
+    }
+    const int err = c->h_counters[kCntError];
+    if ((rc = check_error_bits(err & ~kErrEmpty))) return rc;
+    if (c->h_counters[kCntMiss] > 0) return resolve_misses(c, b, p, a, rp, st, stats);
+    return check_error_bits(err);
+}
+
+// uploads a host batch into the context's staging buffers; returns a batch of device pointers
+int upload_batch(strk_ctx* c, const strk_batch* b, strk_batch* d, hipStream_t st) {
+    if (!b || b->n_reads < 0 || b->n_loci < 0) return fail(STRK_E_INVALID, "bad batch");
+    *d = *b;
+    if (b->n_reads == 0 || b->n_loci == 0) return 0;
+    if (!b->seq_off || !b->nfl || !b->ntr || !b->nfr || !b->read_off || !b->motifs || !b->motif_off)
+        return fail(STRK_E_INVALID, "batch pointer is NULL");
+    const size_t nr = (size_t)b->n_reads, nl = (size_t)b->n_loci;
+    if (b->read_off[0] != 0 || b->read_off[nl] != b->n_reads) return fail(STRK_E_INVALID, "read_off must span [0, n_reads]");
+    for (size_t l = 0; l < nl; ++l) {
+        if (b->read_off[l + 1] < b->read_off[l]) return fail(STRK_E_INVALID, "read_off must be non-decreasing");
+        if (b->motif_off[l + 1] <= b->motif_off[l]) return fail(STRK_E_INVALID, "locus %zu has an empty motif", l);
+    }
+    for (size_t r = 0; r < nr; ++r) {
+        if (b->nfl[r] < 0 || b->ntr[r] < 0 || b->nfr[r] < 0) return fail(STRK_E_INVALID, "read %zu has a negative length", r);
+        if (b->seq_off[r + 1] - b->seq_off[r] != (int64_t)b->nfl[r] + b->ntr[r] + b->nfr[r])
+            return fail(STRK_E_INVALID, "read %zu: seq_off does not match nfl+ntr+nfr", r);
+    }
+    const size_t nbases = (size_t)b->seq_off[nr], nmot = (size_t)b->motif_off[nl];
+    if (nbases && !b->seqs) return fail(STRK_E_INVALID, "seqs is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+#define UP(buf, src, bytes, field)                                                              \
+    if ((rc = c->buf.ensure(std::max<size_t>((bytes), 16)))) return rc;                         \
+    if ((bytes) > 0) HIP_TRY(hipMemcpyAsync(c->buf.p, (src), (bytes), hipMemcpyHostToDevice, st)); \
+    d->field = static_cast<decltype(d->field)>(c->buf.p);
+    UP(in_seqs, b->seqs, nbases, seqs)
+    UP(in_seq_off, b->seq_off, (nr + 1) * 8, seq_off)
+    UP(in_nfl, b->nfl, nr * 4, nfl)
+    UP(in_ntr, b->ntr, nr * 4, ntr)
+    UP(in_nfr, b->nfr, nr * 4, nfr)
+    UP(in_read_off, b->read_off, (nl + 1) * 4, read_off)
+    UP(in_motifs, b->motifs, nmot, motifs)
+    UP(in_motif_off, b->motif_off, (nl + 1) * 4, motif_off)
+    if (b->est_cn) {
+        UP(in_est, b->est_cn, nr * 4, est_cn)
+    } else {
+        if ((rc = c->in_est.ensure(nr * 4))) return rc;
+        HIP_TRY(hipMemsetAsync(c->in_est.p, 0, nr * 4, st));
+        d->est_cn = c->in_est.as<int32_t>();
+    }
+#undef UP
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* strk_last_error(void) { return g_err.c_str(); }
+const char* strk_version(void) { return "strkit_amd 0.1.0 (gfx950)"; }
+
+int strk_init(int device, strk_ctx** out) {
+    if (!out) return fail(STRK_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(STRK_E_NODEV, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(STRK_E_NODEV, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(STRK_E_NODEV, "device %d is %s; this library holds gfx950 code objects only", device, prop.gcnArchName);
+    strk_ctx* c = new strk_ctx();
+    c->device = device;
+    strk::ScoreTables t;
+    strk::build_score_tables(&t);
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(strk::c_mat), t.mat, sizeof t.mat);
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(strk::c_enc), t.enc, sizeof t.enc);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), kCountersBytes, hipHostMallocDefault);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+        strk_destroy(c);
+        return fail(STRK_E_DEVICE, "context setup: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return 0;
+}
+
+void strk_destroy(strk_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    DevBuf* bufs[] = {&c->read_locus, &c->win_lo, &c->win_n, &c->tab_off, &c->table, &c->cls_list, &c->counters,
+                      &c->scratch, &c->state_i32, &c->state_f64, &c->win_lo2, &c->win_n2, &c->tab_off2, &c->table2,
+                      &c->items, &c->in_seqs, &c->in_seq_off, &c->in_nfl, &c->in_ntr, &c->in_nfr, &c->in_est,
+                      &c->in_read_off, &c->in_motifs, &c->in_motif_off, &c->out_cn, &c->out_score, &c->out_n,
+                      &c->out_start};
+    for (DevBuf* b : bufs) b->release();
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int strk_count_loci_device(strk_ctx* ctx, const strk_batch* batch, const strk_params* params, int32_t* out_cn,
+                           int32_t* out_score, int32_t* out_n_iters, int32_t* out_start, void* stream,
+                           strk_stats* stats) {
+    if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
+    return count_device(ctx, batch, params, out_cn, out_score, out_n_iters, out_start, static_cast<hipStream_t>(stream), stats);
+}
+
+int strk_count_loci(strk_ctx* ctx, const strk_batch* batch, const strk_params* params, int32_t* out_cn,
+                    int32_t* out_score, int32_t* out_n_iters, int32_t* out_start, strk_stats* stats) {
+    if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
+    if (stats) memset(stats, 0, sizeof *stats);
+    strk_batch d;
+    int rc;
+    if ((rc = upload_batch(ctx, batch, &d, nullptr))) return rc;
+    if (batch->n_reads == 0 || batch->n_loci == 0) return 0;
+    if (!batch->est_cn) return fail(STRK_E_INVALID, "est_cn is NULL");
+    const size_t nb = (size_t)batch->n_reads * 4;
+    if ((rc = ctx->out_cn.ensure(nb)) || (rc = ctx->out_score.ensure(nb)) || (rc = ctx->out_n.ensure(nb)) ||
+        (rc = ctx->out_start.ensure(nb)))
+        return rc;
+    rc = count_device(ctx, &d, params, ctx->out_cn.as<int32_t>(), ctx->out_score.as<int32_t>(), ctx->out_n.as<int32_t>(),
+                      ctx->out_start.as<int32_t>(), nullptr, stats);
+    if (rc && rc != STRK_E_EMPTY) return rc;
+    const int rc_keep = rc;
+    if (out_cn) HIP_TRY(hipMemcpy(out_cn, ctx->out_cn.p, nb, hipMemcpyDeviceToHost));
+    if (out_score) HIP_TRY(hipMemcpy(out_score, ctx->out_score.p, nb, hipMemcpyDeviceToHost));
+    if (out_n_iters) HIP_TRY(hipMemcpy(out_n_iters, ctx->out_n.p, nb, hipMemcpyDeviceToHost));
+    if (out_start) HIP_TRY(hipMemcpy(out_start, ctx->out_start.p, nb, hipMemcpyDeviceToHost));
+    return rc_keep;
+}
+
+int strk_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int32_t tr_len, const uint8_t* fl,
+                      int32_t fl_len, const uint8_t* fr, int32_t fr_len, const uint8_t* motif, int32_t motif_len,
+                      int32_t max_iters, int32_t local_search_range, int32_t step_size, int32_t* out_cn,
+                      int32_t* out_score, int32_t* out_n_explored) {
+    if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
+    if (tr_len < 0 || fl_len < 0 || fr_len < 0 || motif_len < 1) return fail(STRK_E_INVALID, "bad sequence length");
+    if ((tr_len && !tr) || (fl_len && !fl) || (fr_len && !fr) || !motif) return fail(STRK_E_INVALID, "sequence pointer is NULL");
+    std::vector<uint8_t> seq((size_t)fl_len + tr_len + fr_len);
+    if (fl_len) memcpy(seq.data(), fl, (size_t)fl_len);
+    if (tr_len) memcpy(seq.data() + fl_len, tr, (size_t)tr_len);
+    if (fr_len) memcpy(seq.data() + fl_len + tr_len, fr, (size_t)fr_len);
+    const int64_t seq_off[2] = {0, (int64_t)seq.size()};
+    const int32_t read_off[2] = {0, 1}, motif_off[2] = {0, motif_len};
+    strk_batch b;
+    b.n_reads = 1; b.n_loci = 1;
+    b.seqs = seq.data(); b.seq_off = seq_off; b.nfl = &fl_len; b.ntr = &tr_len; b.nfr = &fr_len;
+    b.est_cn = &start_count; b.read_off = read_off; b.motifs = motif; b.motif_off = motif_off;
+    strk_params p;
+    memset(&p, 0, sizeof p);
+    p.max_iters = max_iters; p.local_search_range = local_search_range; p.step_size = step_size;
+    p.tie_rule = STRK_TIE_FIRST; p.end_flags = STRK_SG_ALL; p.feedback = 0;
+    p.window = std::min(15, std::max(kDefaultWindow, local_search_range + step_size + 1));
+    int32_t cn = 0, sc = 0, n = 0, st = 0;
+    const int rc = strk_count_loci(ctx, &b, &p, &cn, &sc, &n, &st, nullptr);
+    if (rc) return rc;
+    if (out_cn) *out_cn = cn;
+    if (out_score) *out_score = sc;
+    if (out_n_explored) *out_n_explored = n;
+    return 0;
+}
+
+int strk_score_table(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, const int32_t* n,
+                     const int64_t* table_off, int32_t end_flags, int32_t force_generic, int32_t* scores,
+                     strk_stats* stats) {
+    if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (end_flags < 0 || end_flags > 15) return fail(STRK_E_INVALID, "bad end_flags");
+    strk_batch d;
+    int rc;
+    if ((rc = upload_batch(ctx, batch, &d, nullptr))) return rc;
+    if (batch->n_reads == 0 || batch->n_loci == 0) return 0;
+    if (!lo || !n || !table_off || !scores) return fail(STRK_E_INVALID, "lo / n / table_off / scores is NULL");
+    const size_t nr = (size_t)batch->n_reads;
+    size_t n_chunks = 0;
+    for (size_t r = 0; r < nr; ++r) {
+        if (lo[r] < 0 || n[r] < 0) return fail(STRK_E_INVALID, "read %zu: negative window", r);
+        if (table_off[r + 1] - table_off[r] < n[r] || table_off[r] < 0) return fail(STRK_E_INVALID, "read %zu: table_off too small", r);
+        n_chunks += ((size_t)n[r] + kTableMax - 1) / kTableMax;
+    }
+    const size_t tab = (size_t)table_off[nr];
+    if ((rc = ensure_workspace(ctx, batch->n_reads, batch->n_loci, tab, std::max<size_t>(n_chunks, 1)))) return rc;
+    KArgs a = make_args(ctx, &d, end_flags, 0, 0, (int)std::max<size_t>(n_chunks, 1));
+    hipStream_t st = nullptr;
+    HIP_TRY(hipMemcpyAsync(a.win_lo, lo, nr * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(a.win_n, n, nr * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(a.tab_off, table_off, nr * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, kCountersBytes, st));
+    HIP_TRY(hipEventRecord(ctx->ev[0], st));
+    enqueue_scoring(ctx, a, 1, nullptr, batch->n_reads, force_generic, st, true);
+    HIP_TRY(hipEventRecord(ctx->ev[3], st));
+    HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if ((rc = check_error_bits(ctx->h_counters[kCntError]))) return rc;
+    if (tab) HIP_TRY(hipMemcpy(scores, a.table, tab * 4, hipMemcpyDeviceToHost));
+    if (stats) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) stats->kernel_ms = ms;
+        if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) stats->dp_kernel_ms = ms;
+        stats->n_dp_launches = kNumClasses + 1;
+        stats->n_fallback = ctx->h_counters[kCntClass0 + kGenericClass];
+        stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->h_counters) + kCellsOff);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+"""Shared generators for the parity tests (seeded; no reference code involved)."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle
+from strkit_amd.synth import LocusBatch
+
+ALPHA_ACGT = "ACGT"
+ALPHA_WC = "ACGTXN"
+ALPHA_IUPAC = "ACGTRYSWKMBDHVNX"
+
+
+def rand_seq(rng, n, alpha=ALPHA_ACGT):
+    return "".join(alpha[i] for i in rng.integers(len(alpha), size=n))
+
+
+def noisy_tract(rng, motif, cn, n_edits, alpha):
+    tr = list(motif * cn)
+    for _ in range(n_edits):
+        x = rng.random()
+        if tr and x < 0.4:
+            tr[rng.integers(len(tr))] = alpha[rng.integers(len(alpha))]
+        elif tr and x < 0.7:
+            del tr[rng.integers(len(tr))]
+        else:
+            tr.insert(int(rng.integers(len(tr) + 1)), alpha[rng.integers(len(alpha))])
+    return "".join(tr)
+
+
+def random_locus(rng, n_reads, motif_len=(1, 6), cn=(0, 40), flank=(1, 80), alpha=ALPHA_ACGT, motif_alpha=None,
+                 edits=(0, 4)):
+    m = int(rng.integers(motif_len[0], motif_len[1] + 1))
+    motif = rand_seq(rng, m, motif_alpha or alpha)
+    fl0 = rand_seq(rng, int(rng.integers(flank[0], flank[1] + 1)), alpha)
+    fr0 = rand_seq(rng, int(rng.integers(flank[0], flank[1] + 1)), alpha)
+    base_cn = int(rng.integers(cn[0], cn[1] + 1))
+    reads = []
+    for _ in range(n_reads):
+        c = max(0, base_cn + int(rng.integers(-2, 3)))
+        tr = noisy_tract(rng, motif, c, int(rng.integers(edits[0], edits[1] + 1)), alpha)
+        fl = noisy_tract(rng, fl0, 1, int(rng.integers(0, 2)), alpha) or fl0
+        fr = noisy_tract(rng, fr0, 1, int(rng.integers(0, 2)), alpha) or fr0
+        reads.append((fl, tr, fr))
+    return motif, reads
+
+
+def oracle_table(b: LocusBatch, lo, n, flags=15):
+    out = []
+    for l in range(b.n_loci):
+        motif = b.motif(l)
+        for r in range(int(b.read_off[l]), int(b.read_off[l + 1])):
+            fl, tr, fr = b.read(r)
+            out.append(np.array([oracle.candidate_score(tr, fl, fr, motif, int(lo[r]) + k, flags)
+                                 for k in range(int(n[r]))], np.int32))
+    return out
+
+
+def oracle_count(b: LocusBatch, max_iters=50, lsr=3, step=1, tie_rule=0, flags=15, feedback=True):
+    res = {k: np.zeros(b.n_reads, np.int32) for k in ("cn", "score", "n_iters", "start")}
+    for l in range(b.n_loci):
+        r0, r1 = int(b.read_off[l]), int(b.read_off[l + 1])
+        if r1 == r0:
+            continue
+        s0 = int(b.seq_off[r0])
+        o = oracle.count_locus(b.seqs[s0:int(b.seq_off[r1])], b.seq_off[r0:r1 + 1] - s0, b.nfl[r0:r1], b.ntr[r0:r1],
+                               b.nfr[r0:r1], b.est_cn[r0:r1], b.motif(l), max_iters, lsr, step, tie_rule, flags,
+                               feedback)
+        for k in res:
+            res[k][r0:r1] = o[k]
+    return res

@@ -1,0 +1,82 @@
+"""GPU parity of the whole per-read path (DP + search + caller feedback) vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from helpers import ALPHA_WC, oracle_count, random_locus
+from strkit_amd.synth import LocusBatch, make_config
+
+pytestmark = pytest.mark.gpu
+KEYS = ("cn", "score", "n_iters", "start")
+
+
+def _compare(b, got, exp):
+    for k in KEYS:
+        bad = np.nonzero(got[k] != exp[k])[0]
+        assert bad.size == 0, f"{k}: {bad.size} of {b.n_reads} reads differ; first read {bad[0]}: " \
+                              f"got {[int(got[x][bad[0]]) for x in KEYS]} exp {[int(exp[x][bad[0]]) for x in KEYS]} " \
+                              f"{b.read(int(bad[0]))}"
+
+
+def _run(b, ctx, **kw):
+    from strkit_amd.batch import count_loci
+    from strkit_amd.repeat_count_params import RepeatCountParams
+    rc = RepeatCountParams("repalign", kw.pop("max_iters", 50), kw.pop("lsr", 3), kw.pop("step", 1))
+    return count_loci(b, rc, ctx=ctx, with_stats=True, **kw)
+
+
+@pytest.mark.parametrize("cfg,n_loci", [(1, 44), (2, 150), (3, 60)])
+def test_configs_match_oracle(gpu_ctx, cfg, n_loci):
+    b = make_config(cfg, n_loci=n_loci)
+    got, st = _run(b, gpu_ctx)
+    _compare(b, got, oracle_count(b))
+    assert st["dp_cells"] > 0
+
+
+def test_window_miss_path(gpu_ctx):
+    """A 1-wide speculative window forces almost every read through the host-driven miss rounds."""
+    rng = np.random.default_rng(21)
+    loci = [random_locus(rng, 8, motif_len=(2, 6), cn=(5, 30), flank=(30, 70), alpha=ALPHA_WC) for _ in range(40)]
+    b = LocusBatch.from_reads(loci)
+    b.est_cn = np.maximum(0, b.est_cn + rng.integers(-9, 10, size=b.n_reads)).astype(np.int32)  # bad estimates
+    exp = oracle_count(b)
+    for window in (1, 3, 8):
+        got, st = _run(b, gpu_ctx, window=window)
+        _compare(b, got, exp)
+        if window == 1:
+            assert st["n_miss_reads"] > 0
+
+
+@pytest.mark.parametrize("kw", [dict(feedback=False), dict(tie_rule=1), dict(max_iters=5), dict(lsr=1, step=2),
+                                dict(lsr=1, step=15, max_iters=50), dict(end_flags=0), dict(end_flags=10)])
+def test_search_variants(gpu_ctx, kw):
+    rng = np.random.default_rng(22)
+    loci = [random_locus(rng, 6, motif_len=(1, 6), cn=(0, 25), flank=(10, 70), alpha=ALPHA_WC) for _ in range(50)]
+    b = LocusBatch.from_reads(loci)
+    got, _ = _run(b, gpu_ctx, **dict(kw))
+    okw = dict(max_iters=kw.get("max_iters", 50), lsr=kw.get("lsr", 3), step=kw.get("step", 1),
+               tie_rule=kw.get("tie_rule", 0), flags=kw.get("end_flags", 15), feedback=kw.get("feedback", True))
+    _compare(b, got, oracle_count(b, **okw))
+
+
+def test_scalar_get_repeat_count(gpu_ctx):
+    import oracle
+    from strkit_amd.repeat_count_params import default_read_rc_params
+    from strkit_amd.repeats import get_repeat_count
+    rng = np.random.default_rng(23)
+    rc = default_read_rc_params()
+    for _ in range(25):
+        motif, reads = random_locus(rng, 1, cn=(0, 30), flank=(20, 70), alpha=ALPHA_WC)
+        fl, tr, fr = reads[0]
+        start = max(0, round(len(tr) / len(motif)) + int(rng.integers(-12, 13)))
+        assert get_repeat_count(start, tr, fl, fr, motif, rc) == oracle.repeat_count(start, tr, fl, fr, motif)
+
+
+def test_empty_and_ragged_batches(gpu_ctx):
+    from strkit_amd.batch import count_loci
+    empty = LocusBatch.from_reads([])
+    assert count_loci(empty, ctx=gpu_ctx)["cn"].size == 0
+    b = LocusBatch.from_reads([("CAG", []), ("AT", [("ACGTTGCA", "ATATATAT", "GGCCTTAA")]), ("A", [])])
+    got = count_loci(b, ctx=gpu_ctx)
+    exp = oracle_count(b)
+    for k in KEYS:
+        assert np.array_equal(got[k], exp[k])
