@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — reads/s through the per-read repeat-count hot path on MI355X.
+
+One "step" = one pass of the hot path (plan -> DP kernels -> search replay) over one batch of
+synthetic reads that is already resident in HBM: BASELINE.json configs[1]
+(1 000 loci x 30 HiFi reads, motif 3-6 bp, 70 bp flanks).  With --gpus N every rank owns its own
+shard of N x 1 000 loci (weak scaling, loci are independent: strkit/call/call_sample.py:414) and
+the per-read results are collected with one RCCL all-gather per step.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement; extra keys documented in DESIGN.md §6).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+# int32 VALU peak used for the companion figure: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 Tops/s
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+WORKLOAD = "cfg2: 1000 loci x 30 HiFi reads per GPU, motif 3-6 bp, flank 70, exact (unbanded) DP"
+
+
+def _cpu_worker(args):
+    """One CPU process of the baseline: the oracle's per-locus loop over a slice of loci."""
+    cfg, lo, hi, seed_shift = args
+    import oracle  # CPU baseline leg only (test infrastructure, never on the product path)
+    from strkit_amd.synth import make_config
+    b = make_config(cfg, n_loci=hi, seed_shift=seed_shift).locus_slice(lo, hi)
+    t0 = time.perf_counter()
+    cells = 0
+    for l in range(b.n_loci):
+        r0, r1 = int(b.read_off[l]), int(b.read_off[l + 1])
+        s0 = int(b.seq_off[r0])
+        o = oracle.count_locus(b.seqs[s0:int(b.seq_off[r1])], b.seq_off[r0:r1 + 1] - s0, b.nfl[r0:r1], b.ntr[r0:r1],
+                               b.nfr[r0:r1], b.est_cn[r0:r1], b.motif(l))
+        cells += o["cells"]
+    return b.n_reads, time.perf_counter() - t0, cells
+
+
+def cpu_baseline(cfg: int, sample_loci: int) -> dict:
+    """Oracle (CPU restatement of the reference algorithm) on a bounded sample, all host cores,
+    loci sharded over processes as strkit/call/call_sample.py:414 does.  Runs BEFORE HIP is
+    initialised so the forked workers never see a GPU context."""
+    import multiprocessing as mp
+    import oracle
+    oracle.build()
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    per = max(1, sample_loci // cores)
+    jobs = [(cfg, i * per, (i + 1) * per, 0) for i in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    reads = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)
+    return {"value": reads / busy, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"first {per * cores} loci ({reads} reads) of the same workload, scalar C oracle, "
+                      f"{cores} processes, {busy:.1f} s busy ({wall:.1f} s wall incl. input generation)",
+            "reads_per_s_per_core": reads / busy / cores, "gcups": sum(r[2] for r in res) / busy / 1e9}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's own count)")
+    ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--cpu-sample-loci", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+
+    cpu = None
+    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.config, a.cpu_sample_loci)
+
+    import torch
+    import torch.distributed as dist
+    from strkit_amd import _lib
+    from strkit_amd.batch import make_params
+    from strkit_amd.synth import make_config
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- this rank's shard: its own loci (weak scaling), inputs made resident in HBM -----------
+    b = make_config(a.config, n_loci=a.loci, seed_shift=rank)
+    ctx = _lib.Context(local_rank)
+    L = _lib.load()
+    t = dict(seqs=torch.from_numpy(b.seqs).to(dev), seq_off=torch.from_numpy(b.seq_off).to(dev),
+             nfl=torch.from_numpy(b.nfl).to(dev), ntr=torch.from_numpy(b.ntr).to(dev),
+             nfr=torch.from_numpy(b.nfr).to(dev), est_cn=torch.from_numpy(b.est_cn).to(dev),
+             read_off=torch.from_numpy(b.read_off).to(dev), motifs=torch.from_numpy(b.motifs).to(dev),
+             motif_off=torch.from_numpy(b.motif_off).to(dev))
+    sb = _lib.StrkBatch(n_reads=b.n_reads, n_loci=b.n_loci, **{k: v.data_ptr() for k, v in t.items()})
+    out = torch.zeros((4, b.n_reads), dtype=torch.int32, device=dev)  # cn | score | n_iters | start
+    gathered = torch.zeros((world, 4, b.n_reads), dtype=torch.int32, device=dev) if world > 1 else None
+    p = make_params(window=a.window)
+    st = _lib.StrkStats()
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        rc = L.strk_count_loci_device(ctx.handle, C.byref(sb), C.byref(p), out[0].data_ptr(), out[1].data_ptr(),
+                                      out[2].data_ptr(), out[3].data_ptr(), C.c_void_p(stream.cuda_stream), C.byref(st))
+        _lib.check(rc)
+        if world > 1:  # collect per-read results of every shard (RCCL all-gather over xGMI)
+            dist.all_gather_into_tensor(gathered, out)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    dp_ms, all_ms, misses, fallback = 0.0, 0.0, 0, 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        dp_ms += st.dp_kernel_ms
+        all_ms += st.kernel_ms
+        misses += st.n_miss_reads
+        fallback += st.n_fallback
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([b.n_reads, b.n_loci], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        n_reads_all, n_loci_all = int(tot[0]), int(tot[1])
+    else:
+        n_reads_all, n_loci_all = b.n_reads, b.n_loci
+
+    if rank == 0:
+        # sanity: the timed path's answers on the first loci agree with the oracle (checker only)
+        import oracle
+        chk = b.locus_slice(0, min(8, b.n_loci))
+        got = out[:, :chk.n_reads].cpu().numpy()
+        parity = "ok"
+        for l in range(chk.n_loci):
+            r0, r1 = int(chk.read_off[l]), int(chk.read_off[l + 1])
+            s0 = int(chk.seq_off[r0])
+            o = oracle.count_locus(chk.seqs[s0:int(chk.seq_off[r1])], chk.seq_off[r0:r1 + 1] - s0, chk.nfl[r0:r1],
+                                   chk.ntr[r0:r1], chk.nfr[r0:r1], chk.est_cn[r0:r1], chk.motif(l))
+            for i, k in enumerate(("cn", "score", "n_iters", "start")):
+                if not np.array_equal(got[i, r0:r1], o[k]):
+                    parity = f"MISMATCH locus {l} field {k}"
+        alg_bytes = b.algorithmic_bytes()
+        dp_s = dp_ms / a.steps / 1e3
+        cells = int(st.dp_cells)
+        line = {
+            "metric": "reads/sec realigned", "value": n_reads_all * a.steps / elapsed, "unit": "reads/s",
+            "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": WORKLOAD if a.config == 2 and a.loci is None else f"cfg{a.config}, {b.n_loci} loci per GPU",
+                       "loci_per_gpu": b.n_loci, "reads_per_gpu": b.n_reads, "window": int(p.window) or 8,
+                       "parallelism": f"loci-sharded x{a.gpus}" + (" + all_gather" if world > 1 else "")},
+            "loci_per_s": n_loci_all * a.steps / elapsed,
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / dp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / dp_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "strk::k_dp<*> (all DP launches of one step)",
+                         "kernel_ms": dp_ms / a.steps, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "integer max-plus DP: the binding unit is VALU issue, see valu"},
+            "valu": {"gcups": cells / dp_s / 1e9, "cells_per_step": cells,
+                     "peak_int32_tops": VALU_PEAK_TOPS, "unit": "G cell updates/s"},
+            "device_ms_per_step": all_ms / a.steps, "window_miss_reads_per_step": misses / a.steps,
+            "generic_kernel_items_per_step": fallback / a.steps,
+            "parity_check": parity,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,23 +101,23 @@ def _mutate(rng: np.random.Generator, seq: np.ndarray, sub: float, indel: float,
     if n == 0:
         return seq
     u = rng.random(n)
-    out = []
-    i = 0
     p_del, p_ins = indel / 2, indel
-    for i in range(n):
-        x = u[i]
-        if x < p_del:
-            continue
-        if x < p_ins:
-            out.append(_BASES[rng.integers(4)])
-            out.append(seq[i])
-        elif x < p_ins + sub:
-            out.append(_BASES[(np.searchsorted(_BASES, seq[i]) + 1 + rng.integers(3)) % 4])
-        elif x < p_ins + sub + xrate:
-            out.append(_X)
-        else:
-            out.append(seq[i])
-    return np.array(out, np.uint8)
+    is_del = u < p_del
+    is_ins = (u >= p_del) & (u < p_ins)
+    is_sub = (u >= p_ins) & (u < p_ins + sub)
+    is_x = (u >= p_ins + sub) & (u < p_ins + sub + xrate)
+    base = seq.copy()
+    if is_sub.any():
+        k = int(is_sub.sum())
+        base[is_sub] = _BASES[(np.searchsorted(_BASES, seq[is_sub]) + 1 + rng.integers(3, size=k)) % 4]
+    base[is_x] = _X
+    counts = np.where(is_del, 0, np.where(is_ins, 2, 1))
+    out = np.repeat(base, counts)
+    if is_ins.any():
+        starts = np.cumsum(counts) - counts  # output index of the first copy of each input base
+        at = starts[is_ins]
+        out[at] = _BASES[rng.integers(4, size=len(at))]  # the inserted base precedes the original one
+    return out
 
 
 def make_batch(seed: int, n_loci: int, reads_per_locus: int, motif_len: tuple[int, int], cn_range: tuple[int, int],
@@ -169,9 +169,10 @@ CONFIGS = {
 }
 
 
-def make_config(config_id: int, n_loci: int | None = None, **over) -> LocusBatch:
+def make_config(config_id: int, n_loci: int | None = None, seed_shift: int = 0, **over) -> LocusBatch:
+    """BASELINE.json config `config_id`; `seed_shift` gives every rank of a multi-GPU run its own loci."""
     kw = dict(CONFIGS[config_id])
     if n_loci is not None:
         kw["n_loci"] = n_loci
     kw.update(over)
-    return make_batch(0xC0FFEE + config_id, **kw)
+    return make_batch(0xC0FFEE + config_id + 7919 * seed_shift, **kw)
