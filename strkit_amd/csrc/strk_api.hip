@@ -68,7 +68,7 @@ struct DevBuf {
 struct strk_ctx {
     int device = 0;
     // workspace
-    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, counters, scratch, state_i32, state_f64;
+    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, counters, scratch, state_i32, state_f64, spec;
     DevBuf win_lo2, win_n2, tab_off2, table2, items;
     // staging for the host-buffer entry points
     DevBuf in_seqs, in_seq_off, in_nfl, in_ntr, in_nfr, in_est, in_read_off, in_motifs, in_motif_off;
@@ -87,34 +87,6 @@ constexpr size_t kScratchInts = (size_t)16 << 20;  // 64 MiB of int32 rows for t
 // device layout of the `counters` buffer: int32[kCntTotal] | pad | u64 cells | u64 scratch_used
 constexpr size_t kCellsOff = 64 * sizeof(int32_t);
 constexpr size_t kCountersBytes = kCellsOff + 2 * sizeof(unsigned long long);
-
-template <int G, int CL>
-void launch_dp(const KArgs& a, int cls, int max_items, hipStream_t st) {
-    constexpr int gpb = DpLayout<G, CL>::GPB;
-    int grid = (max_items + gpb - 1) / gpb;
-    grid = std::max(1, std::min(grid, 256 * 8));
-    hipLaunchKernelGGL((k_dp<G, CL>), dim3(grid), dim3(256), 0, st, a, cls);
-}
-
-void launch_dp_class(const KArgs& a, int cls, int max_items, hipStream_t st) {
-    switch (cls) {
-    case 0: launch_dp<16, 8>(a, cls, max_items, st); break;
-    case 1: launch_dp<16, 12>(a, cls, max_items, st); break;
-    case 2: launch_dp<16, 16>(a, cls, max_items, st); break;
-    case 3: launch_dp<16, 20>(a, cls, max_items, st); break;
-    case 4: launch_dp<16, 24>(a, cls, max_items, st); break;
-    case 5: launch_dp<16, 28>(a, cls, max_items, st); break;
-    case 6: launch_dp<64, 8>(a, cls, max_items, st); break;
-    case 7: launch_dp<64, 12>(a, cls, max_items, st); break;
-    case 8: launch_dp<64, 16>(a, cls, max_items, st); break;
-    case 9: launch_dp<64, 20>(a, cls, max_items, st); break;
-    case 10: launch_dp<64, 24>(a, cls, max_items, st); break;
-    case 11: launch_dp<64, 28>(a, cls, max_items, st); break;
-    case 12: launch_dp<64, 32>(a, cls, max_items, st); break;
-    default: break;
-    }
-}
-static_assert(kNumClasses == 13, "launch_dp_class covers 13 classes");
 
 int check_params(const strk_params* p, strk_params* out) {
     if (!p) return fail(STRK_E_INVALID, "params is NULL");
@@ -141,6 +113,7 @@ int ensure_workspace(strk_ctx* c, int n_reads, int n_loci, size_t table_ints, si
     if ((rc = c->counters.ensure(kCountersBytes))) return rc;
     if ((rc = c->state_i32.ensure(nl * 3 * 4))) return rc;
     if ((rc = c->state_f64.ensure(nl * 8))) return rc;
+    if ((rc = c->spec.ensure(nr * 16))) return rc;
     if (!c->scratch.p) {
         if ((rc = c->scratch.ensure(kScratchInts * 4))) return rc;
         c->scratch_ints = kScratchInts;
@@ -148,7 +121,8 @@ int ensure_workspace(strk_ctx* c, int n_reads, int n_loci, size_t table_ints, si
     return 0;
 }
 
-KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int table_stride, int list_stride) {
+KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int table_stride, int list_stride,
+                const strk_params* sp) {
     KArgs a;
     memset(&a, 0, sizeof a);
     a.seqs = b->seqs; a.seq_off = b->seq_off; a.nfl = b->nfl; a.ntr = b->ntr; a.nfr = b->nfr;
@@ -169,6 +143,11 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
     a.end_flags = end_flags;
     a.window = window;
     a.table_stride = table_stride;
+    if (sp) {  // speculative search for start == est_cn inside the DP kernel
+        a.spec = static_cast<int4*>(c->spec.p);
+        a.max_iters = sp->max_iters; a.lsr = sp->local_search_range; a.step = sp->step_size;
+        a.tie_last = sp->tie_rule == STRK_TIE_LAST;
+    }
     return a;
 }
 
@@ -177,8 +156,11 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
                      hipStream_t st, bool time_dp) {
     hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, a, mode, d_items, n_items, force_generic);
     if (time_dp) (void)hipEventRecord(c->ev[1], st);
-    if (!force_generic)
-        for (int cls = 0; cls < kNumClasses; ++cls) launch_dp_class(a, cls, a.list_stride, st);
+    if (!force_generic) {
+        // persistent-style grid: every wave pulls chunks from the device-side queue until it is empty
+        const int blocks = std::max(1, std::min(256 * 4, (a.list_stride + 3) / 4));
+        hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);
+    }
     hipLaunchKernelGGL(k_dp_generic, dim3(256), dim3(256), 0, st, a);
     if (time_dp) (void)hipEventRecord(c->ev[2], st);
 }
@@ -270,6 +252,7 @@ int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs
         a2.table = c->table2.as<int32_t>();
         a2.cls_list = c->cls_list.as<int32_t>();
         a2.list_stride = (int32_t)n_chunks;
+        a2.spec = nullptr;
         HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
         enqueue_scoring(c, a2, 1, c->items.as<int32_t>(), (int)items.size(), 0, st, false);
         HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
@@ -352,7 +335,7 @@ int count_device(strk_ctx* c, const strk_batch* b, const strk_params* params, in
     HIP_TRY(hipSetDevice(c->device));
     const int ts = 2 * p.window + 1;
     if ((rc = ensure_workspace(c, b->n_reads, b->n_loci, (size_t)b->n_reads * ts, (size_t)b->n_reads))) return rc;
-    KArgs a = make_args(c, b, p.end_flags, p.window, ts, b->n_reads);
+    KArgs a = make_args(c, b, p.end_flags, p.window, ts, b->n_reads, &p);
     ReplayArgs rp;
     rp.max_iters = p.max_iters; rp.lsr = p.local_search_range; rp.step = p.step_size;
     rp.tie_last = p.tie_rule == STRK_TIE_LAST; rp.feedback = p.feedback;
@@ -374,7 +357,7 @@ int count_device(strk_ctx* c, const strk_batch* b, const strk_params* params, in
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) stats->kernel_ms = ms;
         if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) stats->dp_kernel_ms = ms;
-        stats->n_dp_launches = kNumClasses + 1;
+        stats->n_dp_launches = 2;
         stats->n_fallback = c->h_counters[kCntClass0 + kGenericClass];
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
     }
@@ -467,7 +450,7 @@ void strk_destroy(strk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->read_locus, &c->win_lo, &c->win_n, &c->tab_off, &c->table, &c->cls_list, &c->counters,
-                      &c->scratch, &c->state_i32, &c->state_f64, &c->win_lo2, &c->win_n2, &c->tab_off2, &c->table2,
+                      &c->scratch, &c->state_i32, &c->state_f64, &c->spec, &c->win_lo2, &c->win_n2, &c->tab_off2, &c->table2,
                       &c->items, &c->in_seqs, &c->in_seq_off, &c->in_nfl, &c->in_ntr, &c->in_nfr, &c->in_est,
                       &c->in_read_off, &c->in_motifs, &c->in_motif_off, &c->out_cn, &c->out_score, &c->out_n,
                       &c->out_start};
@@ -560,7 +543,7 @@ int strk_score_table(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, 
     }
     const size_t tab = (size_t)table_off[nr];
     if ((rc = ensure_workspace(ctx, batch->n_reads, batch->n_loci, tab, std::max<size_t>(n_chunks, 1)))) return rc;
-    KArgs a = make_args(ctx, &d, end_flags, 0, 0, (int)std::max<size_t>(n_chunks, 1));
+    KArgs a = make_args(ctx, &d, end_flags, 0, 0, (int)std::max<size_t>(n_chunks, 1), nullptr);
     hipStream_t st = nullptr;
     HIP_TRY(hipMemcpyAsync(a.win_lo, lo, nr * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(a.win_n, n, nr * 4, hipMemcpyHostToDevice, st));
@@ -578,7 +561,7 @@ int strk_score_table(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, 
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) stats->kernel_ms = ms;
         if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) stats->dp_kernel_ms = ms;
-        stats->n_dp_launches = kNumClasses + 1;
+        stats->n_dp_launches = 2;
         stats->n_fallback = ctx->h_counters[kCntClass0 + kGenericClass];
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->h_counters) + kCellsOff);
     }

@@ -12,7 +12,7 @@
 //     one backward DP over the fr rows give every S[i] as max_j(Gf(R_i,j) + Gb(j)) - const at the
 //     "fork rows" R_i = |fl| + i*|motif| (exact because gaps are linear, so DP nodes carry no
 //     affine state).  ~8x fewer cell updates than one DP per candidate.
-//   * A read is owned by a group of G lanes (16 or 64); each lane keeps CL consecutive db columns
+//   * A read is owned by a group of G lanes (16, 32 or 64); each lane keeps CL consecutive db columns
 //     of the DP row in VGPRs and the group runs a skewed (anti-diagonal) systolic wavefront: lane
 //     l works on row t-l at step t and hands its last column to lane l+1 with one DPP row/wave
 //     shift.  Substitution scores come from one v_perm_b32 per 4 cells on an 8-byte per-row word
@@ -29,13 +29,16 @@ namespace strk {
 
 constexpr int kTableMax = 32;       // max candidates per read in one DP item
 constexpr int kNegInf = -(1 << 29);
-constexpr int kRowSlack = 512;      // a class of capacity CAP accepts up to CAP + kRowSlack prefix rows
+constexpr int kRowSlack = 160;      // a class of capacity CAP accepts up to CAP + kRowSlack prefix rows
 
 // Fast-kernel classes: (G lanes per read, CL columns per lane); capacity = G*CL slots >= |db| + 1.
-constexpr int kNumClasses = 13;
+//   classes 0-5  : G = 16, CL = 8..28   (capacity 128..448,  4 reads per wave)
+//   classes 6-9  : G = 32, CL = 16..28  (capacity 512..896,  2 reads per wave)
+//   classes 10-13: G = 64, CL = 16..28  (capacity 1024..1792, 1 read per wave)
+constexpr int kNumClasses = 14;
 constexpr int kGenericClass = kNumClasses;  // index of the generic list
-__host__ __device__ constexpr int class_G(int c) { return c < 6 ? 16 : 64; }
-__host__ __device__ constexpr int class_CL(int c) { return c < 6 ? 8 + 4 * c : 8 + 4 * (c - 6); }
+__host__ __device__ constexpr int class_G(int c) { return c < 6 ? 16 : (c < 10 ? 32 : 64); }
+__host__ __device__ constexpr int class_CL(int c) { return c < 6 ? 8 + 4 * c : (c < 10 ? 16 + 4 * (c - 6) : 16 + 4 * (c - 10)); }
 __host__ __device__ constexpr int class_cap(int c) { return class_G(c) * class_CL(c); }
 
 __constant__ int8_t c_mat[kNSym][kNSym];
@@ -59,27 +62,31 @@ struct KArgs {
     int32_t* win_n;       // [n_reads]
     int64_t* tab_off;     // [n_reads]
     int32_t* table;       // score table
-    int32_t* cls_list;    // [(kNumClasses + 1) * list_stride]
+    int32_t* cls_list;    // [(kNumClasses + 1) * list_stride * 2]  (read, chunk start) pairs
     int32_t* counters;    // see Counter enum
     unsigned long long* cells;  // DP cells executed
     int32_t* scratch;     // generic kernel rows
     long long scratch_cap;      // in int32 units
     unsigned long long* scratch_used;
+    int4* spec;           // [n_reads] speculative search result for start == est_cn (or NULL)
     int32_t list_stride;
     int32_t end_flags;
     int32_t window;       // half width (plan kernel)
     int32_t table_stride; // entries per read (plan kernel)
+    int32_t max_iters, lsr, step, tie_last;  // search parameters (speculative search in k_dp_all)
 };
 
 enum Counter {
     kCntClass0 = 0,                       // [0..kNumClasses] list lengths (kNumClasses = generic)
     kCntMiss = kNumClasses + 1,           // loci whose search left the table window
     kCntError = kNumClasses + 2,          // sticky error bits
-    kCntTotal = kNumClasses + 3
+    kCntNextChunk = kNumClasses + 3,      // work queue head of k_dp_all
+    kCntTotal = kNumClasses + 4
 };
 constexpr int kErrBadInput = 1;   // empty motif / negative length
 constexpr int kErrScratch = 2;    // generic scratch exhausted
 constexpr int kErrEmpty = 4;      // nothing scored for some read
+constexpr int kSpecMiss = 1, kSpecEmpty = 2;
 
 // ---------------------------------------------------------------------------------------------
 // Plan: per read -> locus id, candidate window, table slot, kernel class.
@@ -98,61 +105,79 @@ __device__ inline int classify(int nfl, int ntr, int nfr, int m, int lo, int n, 
 // mode 0: windows from est_cn +/- window, table slot r*table_stride;
 // mode 1: windows and table offsets are already in win_lo / win_n / tab_off (strk_score_table,
 //         window-miss rounds); `items` (optional) restricts the launch to a list of reads.
-__global__ void k_plan(KArgs a, int mode, const int32_t* items, int n_items, int force_generic) {
+// Class lists are filled with one global atomic per class per block (LDS histogram first).
+__global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* items, int n_items, int force_generic) {
+    __shared__ int s_cnt[kNumClasses + 1];
+    __shared__ int s_base[kNumClasses + 1];
+    __shared__ unsigned long long s_cells;
+    if (threadIdx.x <= kNumClasses) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_cells = 0;
+    __syncthreads();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n_items) return;
-    const int r = items ? items[gid] : gid;
-    // locus of read r: last l with read_off[l] <= r
-    int lo_l = 0, hi_l = a.n_loci;
-    while (hi_l - lo_l > 1) {
-        const int mid = (lo_l + hi_l) >> 1;
-        if (a.read_off[mid] <= r) lo_l = mid; else hi_l = mid;
+    int r = 0, nfl = 0, ntr = 0, nfr = 0, m = 1, lo = 0, n = 0;
+    if (gid < n_items) {
+        r = items ? items[gid] : gid;
+        // locus of read r: last l with read_off[l] <= r
+        int lo_l = 0, hi_l = a.n_loci;
+        while (hi_l - lo_l > 1) {
+            const int mid = (lo_l + hi_l) >> 1;
+            if (a.read_off[mid] <= r) lo_l = mid; else hi_l = mid;
+        }
+        const int l = lo_l;
+        a.read_locus[r] = l;
+        m = a.motif_off[l + 1] - a.motif_off[l];
+        nfl = a.nfl[r]; ntr = a.ntr[r]; nfr = a.nfr[r];
+        if (m < 1 || nfl < 0 || ntr < 0 || nfr < 0) {
+            atomicOr(&a.counters[kCntError], kErrBadInput);
+            a.win_n[r] = 0;
+            n = 0;
+        } else if (mode == 0) {
+            const long long est = a.est_cn[r];
+            long long w_lo = est - a.window, w_hi = est + a.window;
+            if (w_lo < 0) w_lo = 0;
+            if (w_hi < w_lo) w_hi = w_lo;  // negative estimates: keep a one-entry window at 0
+            if (w_hi - w_lo + 1 > a.table_stride) w_hi = w_lo + a.table_stride - 1;
+            lo = (int)w_lo;
+            n = (int)(w_hi - w_lo + 1);
+            a.win_lo[r] = lo;
+            a.win_n[r] = n;
+            a.tab_off[r] = (int64_t)r * a.table_stride;
+        } else {
+            lo = a.win_lo[r];
+            n = a.win_n[r];
+        }
     }
-    const int l = lo_l;
-    a.read_locus[r] = l;
-    const int m = a.motif_off[l + 1] - a.motif_off[l];
-    const int nfl = a.nfl[r], ntr = a.ntr[r], nfr = a.nfr[r];
-    if (m < 1 || nfl < 0 || ntr < 0 || nfr < 0) {
-        atomicOr(&a.counters[kCntError], kErrBadInput);
-        a.win_n[r] = 0;
-        return;
-    }
-    int lo, n;
-    if (mode == 0) {
-        const long long est = a.est_cn[r];
-        long long w_lo = est - a.window, w_hi = est + a.window;
-        if (w_lo < 0) w_lo = 0;
-        if (w_hi < w_lo) w_hi = w_lo;  // negative estimates: keep a one-entry window at 0
-        if (w_hi - w_lo + 1 > a.table_stride) w_hi = w_lo + a.table_stride - 1;
-        lo = (int)w_lo;
-        n = (int)(w_hi - w_lo + 1);
-        a.win_lo[r] = lo;
-        a.win_n[r] = n;
-        a.tab_off[r] = (int64_t)r * a.table_stride;
-    } else {
-        lo = a.win_lo[r];
-        n = a.win_n[r];
-    }
-    if (n <= 0) return;
     // Long windows (window-miss rounds, explicit tables) are cut into items of <= kTableMax sizes.
+    unsigned long long cells = 0;
+    const unsigned long long ndb = (unsigned long long)nfl + ntr + nfr;
     for (int k0 = 0; k0 < n; k0 += kTableMax) {
         const int nn = min(kTableMax, n - k0);
         const int c = classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic);
-        const int idx = atomicAdd(&a.counters[kCntClass0 + c], 1);
-        // item encoding: read index and chunk start are stored side by side
+        atomicAdd(&s_cnt[c], 1);
+        if (c == kGenericClass) {
+            for (int k = 0; k < nn; ++k) cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + k) * m + nfr);
+        } else {
+            cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
+        }
+    }
+    if (cells) atomicAdd(&s_cells, cells);
+    __syncthreads();
+    if (threadIdx.x <= kNumClasses) {
+        const int c = threadIdx.x;
+        s_base[c] = s_cnt[c] ? atomicAdd(&a.counters[kCntClass0 + c], s_cnt[c]) : 0;
+        s_cnt[c] = 0;
+    }
+    if (threadIdx.x == 0 && s_cells) atomicAdd(a.cells, s_cells);
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += kTableMax) {
+        const int nn = min(kTableMax, n - k0);
+        const int c = classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic);
+        const int idx = s_base[c] + atomicAdd(&s_cnt[c], 1);
         if (idx < a.list_stride) {
             a.cls_list[(size_t)c * a.list_stride * 2 + 2 * idx] = r;
             a.cls_list[(size_t)c * a.list_stride * 2 + 2 * idx + 1] = k0;
         } else {
             atomicOr(&a.counters[kCntError], kErrScratch);
-        }
-        const unsigned long long ndb = (unsigned long long)nfl + ntr + nfr;
-        if (c == kGenericClass) {
-            unsigned long long cells = 0;
-            for (int k = 0; k < nn; ++k) cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + k) * m + nfr);
-            atomicAdd(a.cells, cells);
-        } else {
-            atomicAdd(a.cells, ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr));
         }
     }
 }
@@ -160,17 +185,20 @@ __global__ void k_plan(KArgs a, int mode, const int32_t* items, int n_items, int
 // ---------------------------------------------------------------------------------------------
 // Fast DP kernel
 // ---------------------------------------------------------------------------------------------
-template <int G> struct Lanes;
-template <> struct Lanes<16> {
-    // row_shr:1 / row_shl:1 — a 16-lane DPP row is exactly one group
-    static __device__ __forceinline__ int from_left(int keep, int v) { return __builtin_amdgcn_update_dpp(keep, v, 0x111, 0xf, 0xf, false); }
-    static __device__ __forceinline__ int from_right(int keep, int v) { return __builtin_amdgcn_update_dpp(keep, v, 0x101, 0xf, 0xf, false); }
-};
-template <> struct Lanes<64> {
-    // wave_shr:1 / wave_shl:1 (gfx9 DPP controls, present on gfx950)
-    static __device__ __forceinline__ int from_left(int keep, int v) { return __builtin_amdgcn_update_dpp(keep, v, 0x138, 0xf, 0xf, false); }
-    static __device__ __forceinline__ int from_right(int keep, int v) { return __builtin_amdgcn_update_dpp(keep, v, 0x130, 0xf, 0xf, false); }
-};
+constexpr int kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;  // gfx9 DPP controls, present on gfx950
+constexpr int kCLMax = 28;   // columns per lane of the largest class
+constexpr int kNQMax = kCLMax / 4;
+
+// lane l gets v of lane l-1 (wave_shr:1); the first lane of every group gets `keep` instead
+__device__ __forceinline__ int from_left(int keep, int v, bool first) {
+    const int x = __builtin_amdgcn_update_dpp(keep, v, kDppWaveShr1, 0xf, 0xf, false);
+    return first ? keep : x;
+}
+// lane l gets v of lane l+1 (wave_shl:1); the last lane of every group gets `keep` instead
+__device__ __forceinline__ int from_right(int keep, int v, bool last) {
+    const int x = __builtin_amdgcn_update_dpp(keep, v, kDppWaveShl1, 0xf, 0xf, false);
+    return last ? keep : x;
+}
 
 // LDS operations of one group never leave its wave: order them with a wave-level fence.
 __device__ __forceinline__ void wave_lds_sync() {
@@ -179,295 +207,385 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int G>
+// max over the (at most four) groups of a wave of a value that is uniform inside each group
 __device__ __forceinline__ int wave_max_over_groups(int v) {
-    int m = __builtin_amdgcn_readlane(v, 0);
-#pragma unroll
-    for (int g = 1; g < 64 / G; ++g) m = max(m, __builtin_amdgcn_readlane(v, g * G));
-    return m;
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-template <int G, int CL>
+// Per-group LDS layout of a class (G lanes x CL columns); all offsets are multiples of 16.
 struct DpLayout {
-    static constexpr int CAP = G * CL;
-    static constexpr int NGW = 64 / G;           // groups per wave
-    static constexpr int GPB = 4 * NGW;          // groups per 256-thread block
-    static constexpr int ROWS_MAX = CAP + kRowSlack;
-    static constexpr int OFF_TBL = 0;                                   // 18 x 8 B row words
-    static constexpr int OFF_COMB = OFF_TBL + 18 * 8;                   // kTableMax ints
-    static constexpr int OFF_LMAX = OFF_COMB + kTableMax * 4;           // kTableMax ints
-    static constexpr int OFF_MISC = OFF_LMAX + kTableMax * 4;           // 4 ints: symmask, zfree
-    static constexpr int OFF_DB = OFF_MISC + 16;                        // CAP bytes
-    static constexpr int OFF_CP = OFF_DB + CAP;                         // prefix rows
-    static constexpr int LEN_CP = (ROWS_MAX + 2 * G + 15) & ~15;
-    static constexpr int OFF_CT = OFF_CP + LEN_CP;                      // tail rows (reversed fr)
-    static constexpr int LEN_CT = (CAP + 2 * G + 15) & ~15;
-    static constexpr int GROUP_BYTES = (OFF_CT + LEN_CT + 15) & ~15;
+    int cap, off_db, off_cp, off_ct, off_b0, group_bytes;
+    static constexpr int OFF_TBL = 0;                          // 18 x 8 B row words
+    static constexpr int OFF_COMB = OFF_TBL + 18 * 8;          // kTableMax ints
+    static constexpr int OFF_LMAX = OFF_COMB + kTableMax * 4;  // kTableMax ints
+    static constexpr int OFF_MISC = OFF_LMAX + kTableMax * 4;  // 4 ints: symmask, zfree
+    __host__ __device__ constexpr DpLayout(int G, int CL)
+        : cap(G * CL),
+          off_db(OFF_MISC + 16),                                             // 4 pad + CAP + 4 pad bytes
+          off_cp(off_db + ((G * CL + 8 + 15) & ~15)),                        // prefix rows
+          off_ct(off_cp + ((G * CL + kRowSlack + 2 * G + 4 + 15) & ~15)),    // tail rows (reversed fr)
+          off_b0(off_ct + ((G * CL + 2 * G + 4 + 15) & ~15)),                // backward result, u16 per slot
+          group_bytes(off_b0 + ((G * CL * 2 + 15) & ~15)) {}
+};
+__host__ __device__ constexpr int wave_lds_bytes(int c) { return (64 / class_G(c)) * DpLayout(class_G(c), class_CL(c)).group_bytes; }
+__host__ __device__ constexpr int max_wave_lds_bytes(int c) {
+    return c < 0 ? 0 : (wave_lds_bytes(c) > max_wave_lds_bytes(c - 1) ? wave_lds_bytes(c) : max_wave_lds_bytes(c - 1));
+}
+constexpr int kWaveLdsBytes = max_wave_lds_bytes(kNumClasses - 1);
+constexpr int kLdsSlack = 2048 + 256;  // stale row symbols (any byte) may index up to 255*8 B past a row-word table
+
+typedef const __attribute__((address_space(4))) KArgs* KArgsKernarg;
+
+// Everything the two DP passes of one wave need; G and CL are wave-uniform run-time values.
+struct PassCtx {
+    int G, CL, lig;
+    bool first, last, act;
+    int ndb;
+    bool dbBeg, dbEnd, cBeg, cEnd;
+    const uint2* tbl;        // LDS: per-symbol row words
+    const unsigned* selw;    // LDS: selector words of this lane, selw[q] <-> db[lig*CL + 4q - 4 .. -1]
+    uint2* b0;               // LDS: backward result of this lane, b0[q * G] <-> slots 4q..4q+3 (u16 each)
 };
 
-template <int G, int CL>
-__global__ void __launch_bounds__(256) k_dp(KArgs a, int cls) {
-    using L = DpLayout<G, CL>;
+// One DP row in G-space over the lane's 4*NQ columns: dst = max3(up, left, diag + w).  FWD walks
+// the columns left to right, the backward pass right to left; src/dst alternate (no register copies).
+template <int NQ, bool FWD>
+__device__ __forceinline__ int dp_row(const int (&src)[4 * NQ], int (&dst)[4 * NQ], const unsigned (&sel)[NQ], uint2 word,
+                                      int edge, int edge_prev) {
+    int d = edge_prev, l = edge;
+#pragma unroll
+    for (int i = 0; i < 4 * NQ; ++i) {
+        const int c = FWD ? i : 4 * NQ - 1 - i;
+        const unsigned wb = __builtin_amdgcn_perm(word.y, word.x, sel[c / 4]);
+        const int nh = max(max(src[c], l), d + (int)((wb >> (8 * (c % 4))) & 0xffu));
+        d = src[c]; l = nh; dst[c] = nh;
+    }
+    return l;  // the lane's outgoing column
+}
+
+// Backward pass over the fr rows (k' = 1..rowsT consume fr[rowsT-k']).  Slot s holds node j = s
+// (db chars s.. remain) for s < ndb; slots >= ndb are inert pads that carry the boundary value.
+// Leaves Gb(rowsT, .) in LDS (b0) and returns max_{k'<rowsT} (Gb(k', 0) - g*k') for lane 0.
+template <int NQ>
+__device__ __forceinline__ int bwd_pass(const PassCtx& x, int rowsT, const uint8_t* ct) {
+    constexpr int g = kGap, CL = 4 * NQ;
+    int Ha[CL], Hb[CL];
+    unsigned sel[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sel[q] = x.act ? x.selw[q + 1] : 0x0c0c0c0cu;
+#pragma unroll
+    for (int c = 0; c < CL; ++c) {
+        const int s = x.lig * CL + c;
+        int v = 0;
+        if (s < x.ndb && x.dbEnd) v = g * (x.ndb - s) - (s == 0 ? g : 0);
+        Ha[c] = v;
+    }
+    const int G = x.G;
+    const int Tb = (wave_max_over_groups(rowsT > 0 ? rowsT + G - 1 : 0) + 1) & ~1;
+    const int bstep = x.cEnd ? g : 0;
+    const int gkEvent = g * rowsT;
+    int zsave = 0;
+    int hout = Ha[0];
+    int edgePrev = from_right(0, hout, x.last);
+    int gk = g * (x.lig - (G - 1));   // g * k' of the row this lane finished before step 0
+    int zmax = Ha[0];
+    const uint8_t* pa = ct + x.lig;   // row symbol of step t is pa[t]
+    uint2 wordNext = x.tbl[pa[0]];
+    unsigned symNext = pa[1];
+#define STRK_BSTEP(SRC, DST, T)                                                              \
+    {                                                                                        \
+        const uint2 word = wordNext;                                                         \
+        wordNext = x.tbl[symNext];                                                           \
+        symNext = pa[(T) + 2];                                                               \
+        const int edge = from_right(bstep * ((T) + 1), hout, x.last);                        \
+        hout = dp_row<NQ, false>(SRC, DST, sel, word, edge, edgePrev);                       \
+        edgePrev = edge;                                                                     \
+        gk += g;                                                                             \
+        if (gk == gkEvent) {                                                                 \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                   \
+                x.b0[q * G] = make_uint2((unsigned)DST[4 * q] | ((unsigned)DST[4 * q + 1] << 16), \
+                                         (unsigned)DST[4 * q + 2] | ((unsigned)DST[4 * q + 3] << 16)); \
+            zsave = zmax;                                                                    \
+        }                                                                                    \
+        zmax = max(zmax, hout - gk);                                                         \
+        if ((T) == G - 2) zmax = hout;                                                       \
+    }
+    for (int t = 0; t < Tb; t += 2) {
+        STRK_BSTEP(Ha, Hb, t)
+        STRK_BSTEP(Hb, Ha, t + 1)
+    }
+#undef STRK_BSTEP
+    return zsave;
+}
+
+// Forward pass over fl + motif*i_hi.  Slot 0 is an inert pad carrying the left boundary; slot
+// s = 1..ndb holds node j = s (consumes db[s-1]); slots > ndb replicate the last column.  At the
+// fork rows R_k = nfl + (lo+k)*m it folds max_s(Gf + Gb) into comb[k] and records the running
+// last-column maximum in lmaxA[k].
+template <int NQ>
+__device__ __forceinline__ void fwd_pass(const PassCtx& x, int rowsP, const uint8_t* cp, int nEff, int fork0, int m,
+                                         int* comb, int* lmaxA) {
+    constexpr int g = kGap, CL = 4 * NQ;
+    int Ha[CL], Hb[CL];
+    unsigned sel[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sel[q] = x.act ? __builtin_amdgcn_alignbyte(x.selw[q + 1], x.selw[q], 3) : 0x0c0c0c0cu;
+#pragma unroll
+    for (int c = 0; c < CL; ++c) Ha[c] = x.dbBeg ? g * min(x.lig * CL + c, x.ndb) : 0;
+    const int G = x.G;
+    const int Tf = (wave_max_over_groups(nEff > 0 ? rowsP + G - 1 : 0) + 1) & ~1;
+    const int bstep = x.cBeg ? g : 0;
+    const int gm = g * m;
+    int hout = Ha[CL - 1];
+    int edgePrev = from_left(0, hout, x.first);
+    int gr = -g * x.lig;           // g * row this lane finished before step 0
+    int lastmax = kNegInf;
+    int forkG = nEff > 0 ? g * fork0 : 0x7fffffff;
+    int forkIdx = 0;
+    const uint8_t* pa = cp + (G - 1) - x.lig;
+    uint2 wordNext = x.tbl[pa[0]];
+    unsigned symNext = pa[1];
+#define STRK_FSTEP(SRC, DST, T)                                                              \
+    {                                                                                        \
+        const uint2 word = wordNext;                                                         \
+        wordNext = x.tbl[symNext];                                                           \
+        symNext = pa[(T) + 2];                                                               \
+        const int edge = from_left(bstep * ((T) + 1), hout, x.first);                        \
+        hout = dp_row<NQ, true>(SRC, DST, sel, word, edge, edgePrev);                        \
+        edgePrev = edge;                                                                     \
+        gr += g;                                                                             \
+        lastmax = max(lastmax, hout - gr);                                                   \
+        if ((T) == G - 2) lastmax = kNegInf;                                                 \
+        if (gr == forkG) {                                                                   \
+            int acc = kNegInf;                                                               \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                 \
+                const uint2 bw = x.b0[q * G];                                                \
+                acc = max(max(acc, DST[4 * q] + (int)(bw.x & 0xffffu)), DST[4 * q + 1] + (int)(bw.x >> 16)); \
+                acc = max(max(acc, DST[4 * q + 2] + (int)(bw.y & 0xffffu)), DST[4 * q + 3] + (int)(bw.y >> 16)); \
+            }                                                                                \
+            atomicMax(&comb[forkIdx], acc);                                                  \
+            if (x.last) lmaxA[forkIdx] = lastmax;                                            \
+            ++forkIdx;                                                                       \
+            forkG = forkIdx < nEff ? forkG + gm : 0x7fffffff;                                \
+        }                                                                                    \
+    }
+    for (int t = 0; t < Tf; t += 2) {
+        STRK_FSTEP(Ha, Hb, t)
+        STRK_FSTEP(Hb, Ha, t + 1)
+    }
+#undef STRK_FSTEP
+}
+
+// Processes the items [base, base + 64/G) of class list `cls`, one per group of G lanes of this
+// wave.  G (16/32/64) and CL (columns per lane) are wave-uniform run-time values: set-up and
+// epilogue are one body, only the two hot loops are specialised on CL/4 (six copies each).
+// `ap` points at the kernel's KArgs in the kernarg segment: fields are scalar-loaded where they are
+// used instead of living in SGPRs across the hot loops.
+__device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint8_t* Lw) {
     constexpr int g = kGap;
-    constexpr int NQ = CL / 4;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[L::GPB * L::GROUP_BYTES];
-
+    const int G = class_G(cls), CL = class_CL(cls), nq = CL / 4;
+    const DpLayout lay(G, CL);
     const int lane = threadIdx.x & 63;
-    const int lig = lane % G;                       // lane in group
-    const int gib = (threadIdx.x >> 6) * L::NGW + lane / G;  // group in block
-    uint8_t* const Lg = lds + gib * L::GROUP_BYTES;
-    uint2* const tbl = reinterpret_cast<uint2*>(Lg + L::OFF_TBL);
-    int* const comb = reinterpret_cast<int*>(Lg + L::OFF_COMB);
-    int* const lmaxA = reinterpret_cast<int*>(Lg + L::OFF_LMAX);
-    int* const misc = reinterpret_cast<int*>(Lg + L::OFF_MISC);
-    uint8_t* const dbs = Lg + L::OFF_DB;
-    uint8_t* const cp = Lg + L::OFF_CP;
-    uint8_t* const ct = Lg + L::OFF_CT;
+    const int lig = lane & (G - 1);                  // lane in group
+    const int grp = lane / G;
+    const bool first = lig == 0, last = lig == G - 1;
+    uint8_t* const Lg = Lw + grp * lay.group_bytes;
+    uint2* const tbl = reinterpret_cast<uint2*>(Lg + DpLayout::OFF_TBL);
+    int* const comb = reinterpret_cast<int*>(Lg + DpLayout::OFF_COMB);
+    int* const lmaxA = reinterpret_cast<int*>(Lg + DpLayout::OFF_LMAX);
+    int* const misc = reinterpret_cast<int*>(Lg + DpLayout::OFF_MISC);
+    uint8_t* const dbs = Lg + lay.off_db;   // dbs[4 + j] <-> db[j]
+    uint8_t* const cp = Lg + lay.off_cp;
+    uint8_t* const ct = Lg + lay.off_ct;
 
-    const bool dbBeg = a.end_flags & 1, dbEnd = a.end_flags & 2, cBeg = a.end_flags & 4, cEnd = a.end_flags & 8;
-    const int count = min(a.counters[kCntClass0 + cls], a.list_stride);
-    const int32_t* list = a.cls_list + (size_t)cls * a.list_stride * 2;
+    const int end_flags = ap->end_flags;
+    const bool cBeg = end_flags & 4, cEnd = end_flags & 8;
+    const int list_stride = ap->list_stride;
+    const int count = min(ap->counters[kCntClass0 + cls], list_stride);
 
-    for (int base = blockIdx.x * L::GPB; base < count; base += gridDim.x * L::GPB) {
-        const int it = base + gib;
-        bool act = it < count;
-        int r = 0, k0 = 0, nfl = 1, ntr = 0, nfr = 1, m = 1, lo = 0, n = 0;
-        long long soff = 0;
-        const uint8_t* motif = a.motifs;
-        if (act) {
-            r = list[2 * it];
-            k0 = list[2 * it + 1];
-            nfl = a.nfl[r]; ntr = a.ntr[r]; nfr = a.nfr[r];
-            soff = a.seq_off[r];
-            const int l = a.read_locus[r];
-            motif = a.motifs + a.motif_off[l];
-            m = a.motif_off[l + 1] - a.motif_off[l];
-            lo = a.win_lo[r] + k0;
-            n = min(kTableMax, a.win_n[r] - k0);
-        }
-        const int ndb = nfl + ntr + nfr;
-        const int rowsP = act ? nfl + (lo + n - 1) * m : 0;
-        const int rowsT = act ? nfr : 0;
+    const int it = base + grp;
+    bool act = it < count;
+    int r = 0, k0 = 0, nfl = 1, ntr = 0, nfr = 1, m = 1, lo = 0, n = 0;
+    long long soff = 0;
+    const uint8_t* motif = ap->motifs;
+    if (act) {
+        const int32_t* list = ap->cls_list + (size_t)cls * list_stride * 2;
+        r = list[2 * it];
+        k0 = list[2 * it + 1];
+        nfl = ap->nfl[r]; ntr = ap->ntr[r]; nfr = ap->nfr[r];
+        soff = ap->seq_off[r];
+        const int l = ap->read_locus[r];
+        const int mo = ap->motif_off[l];
+        motif += mo;
+        m = ap->motif_off[l + 1] - mo;
+        lo = ap->win_lo[r] + k0;
+        n = min(kTableMax, ap->win_n[r] - k0);
+    }
+    const int ndb = nfl + ntr + nfr;
+    const int rowsP = act ? nfl + (lo + n - 1) * m : 0;
+    const int rowsT = act ? nfr : 0;
 
-        // ---- stage the encoded read window and collect its symbol set --------------------------
-        if (lig == 0) misc[0] = 0;
-        wave_lds_sync();
-        {
-            unsigned mask = 0;
-            for (int s = lig; s < L::CAP; s += G) {
-                int sym = 0xff;
-                if (act && s < ndb) {
-                    sym = c_enc[a.seqs[soff + s]];
-                    mask |= 1u << sym;
-                }
-                dbs[s] = (uint8_t)sym;
+    // ---- stage the encoded read window and collect its symbol set ------------------------------
+    if (first) misc[0] = 0;
+    wave_lds_sync();
+    {
+        unsigned mask = 0;
+        const uint8_t* seq = ap->seqs + soff;
+        for (int s = lig; s < lay.cap + 8; s += G) {
+            int sym = 0xff;
+            const int j = s - 4;
+            if (act && j >= 0 && j < ndb) {
+                sym = c_enc[seq[j]];
+                mask |= 1u << sym;
             }
-            if (mask) atomicOr(reinterpret_cast<unsigned*>(&misc[0]), mask);
+            dbs[s] = (uint8_t)sym;
         }
-        wave_lds_sync();
-        const unsigned symmask = (unsigned)misc[0];
-        const int ncls = __popc(symmask);
-        if (act && ncls > 8) {
-            // more distinct symbols than one v_perm word can hold: hand the item to the generic kernel
-            if (lig == 0) {
-                const int idx = atomicAdd(&a.counters[kCntClass0 + kGenericClass], 1);
-                if (idx < a.list_stride) {
-                    int32_t* gl = a.cls_list + (size_t)kGenericClass * a.list_stride * 2;
-                    gl[2 * idx] = r;
-                    gl[2 * idx + 1] = k0;
-                } else {
-                    atomicOr(&a.counters[kCntError], kErrScratch);
-                }
+        if (mask) atomicOr(reinterpret_cast<unsigned*>(&misc[0]), mask);
+    }
+    wave_lds_sync();
+    const unsigned symmask = (unsigned)misc[0];
+    if (act && __popc(symmask) > 8) {
+        // more distinct symbols than one v_perm word can hold: hand the item to the generic kernel
+        if (first) {
+            int32_t* counters = ap->counters;
+            const int idx = atomicAdd(&counters[kCntClass0 + kGenericClass], 1);
+            if (idx < list_stride) {
+                int32_t* gl = ap->cls_list + (size_t)kGenericClass * list_stride * 2;
+                gl[2 * idx] = r;
+                gl[2 * idx + 1] = k0;
+            } else {
+                atomicOr(&counters[kCntError], kErrScratch);
             }
-            act = false;
         }
-        const int nEff = act ? n : 0;
+        act = false;
+    }
+    const int nEff = act ? n : 0;
 
-        // ---- per-row substitution words: byte k = W(row symbol, k-th db symbol class) + 2g ------
-        for (int e = lig; e < 18; e += G) {
-            unsigned wlo = 0, whi = 0;
-            if (e < kNSym) {
-                int k = 0;
-                for (int s = 0; s < kNSym; ++s) {
-                    if (!((symmask >> s) & 1u)) continue;
-                    if (k < 8) {
-                        const unsigned b = (unsigned)(c_mat[e][s] + kWBias) & 0xffu;
-                        if (k < 4) wlo |= b << (8 * k); else whi |= b << (8 * (k - 4));
-                    }
-                    ++k;
+    // ---- per-row substitution words: byte k = W(row symbol, k-th db symbol class) + 2g ----------
+    for (int e = lig; e < 18; e += G) {
+        unsigned wlo = 0, whi = 0;
+        if (e < kNSym) {
+            int k = 0;
+            for (int s = 0; s < kNSym; ++s) {
+                if (!((symmask >> s) & 1u)) continue;
+                if (k < 8) {
+                    const unsigned b = (unsigned)(c_mat[e][s] + kWBias) & 0xffu;
+                    if (k < 4) wlo |= b << (8 * k); else whi |= b << (8 * (k - 4));
                 }
-            }
-            tbl[e] = make_uint2(wlo, whi);
-        }
-        for (int e = lig; e < kTableMax; e += G) { comb[e] = kNegInf; lmaxA[e] = kNegInf; }
-        // ---- candidate row symbols: null padding | fl | motif*i_hi | null padding --------------
-        {
-            const int lenP = rowsP + 2 * (G - 1);
-            for (int idx = lig; idx < lenP; idx += G) {
-                const int row = idx - (G - 1);  // 0-based row
-                int sym = kNullSym;
-                if (row >= 0 && row < rowsP) sym = row < nfl ? dbs[row] : c_enc[motif[(row - nfl) % m]];
-                cp[idx] = (uint8_t)sym;
-            }
-            const int lenT = rowsT + 2 * (G - 1);
-            for (int idx = lig; idx < lenT; idx += G) {
-                const int row = idx - (G - 1);  // backward row k' - 1
-                int sym = kNullSym;
-                if (row >= 0 && row < rowsT) sym = dbs[nfl + ntr + nfr - 1 - row];
-                ct[idx] = (uint8_t)sym;
+                ++k;
             }
         }
-        wave_lds_sync();
+        tbl[e] = make_uint2(wlo, whi);
+    }
+    for (int e = lig; e < kTableMax; e += G) { comb[e] = kNegInf; lmaxA[e] = kNegInf; }
+    // ---- candidate row symbols: null padding | fl | motif*i_hi | null padding ------------------
+    {
+        const int lenP = rowsP + 2 * (G - 1) + 4;
+        for (int idx = lig; idx < lenP; idx += G) {
+            const int row = idx - (G - 1);  // 0-based row
+            int sym = kNullSym;
+            if (row >= 0 && row < rowsP) sym = row < nfl ? dbs[4 + row] : c_enc[motif[(row - nfl) % m]];
+            cp[idx] = (uint8_t)sym;
+        }
+        const int lenT = rowsT + 2 * (G - 1) + 4;
+        for (int idx = lig; idx < lenT; idx += G) {
+            const int row = idx - (G - 1);  // backward row k' - 1
+            int sym = kNullSym;
+            if (row >= 0 && row < rowsT) sym = dbs[4 + ndb - 1 - row];
+            ct[idx] = (uint8_t)sym;
+        }
+    }
+    wave_lds_sync();
+    // ---- db symbols -> v_perm selector bytes (class id = rank of the symbol's bit; pads -> 0x0c = constant 0)
+    for (int s = lig; s < lay.cap + 8; s += G) {
+        const unsigned sym = dbs[s];
+        dbs[s] = (uint8_t)(sym < (unsigned)kNSym ? __popc(symmask & ((1u << sym) - 1u)) : 0x0c);
+    }
+    wave_lds_sync();
 
-        // class id of a db symbol = rank of its bit in symmask
-        auto sel_of = [&](int slot_char) -> unsigned {  // slot_char: index into db, or -1 for a pad
-            if (slot_char < 0 || slot_char >= ndb) return 0x0cu;  // v_perm: constant 0x00
-            const unsigned sym = dbs[slot_char];
-            return (unsigned)__popc(symmask & ((1u << sym) - 1u));
-        };
+    PassCtx x;
+    x.G = G; x.CL = CL; x.lig = lig; x.first = first; x.last = last; x.act = act; x.ndb = ndb;
+    x.dbBeg = end_flags & 1; x.dbEnd = end_flags & 2; x.cBeg = cBeg; x.cEnd = cEnd;
+    x.tbl = tbl;
+    x.selw = reinterpret_cast<const unsigned*>(dbs) + lig * nq;
+    x.b0 = reinterpret_cast<uint2*>(Lg + lay.off_b0) + lig;
 
-        int H[CL], B0[CL];
-        unsigned sel[NQ];
+    int zsave;
+    switch (nq) {
+    case 2: zsave = bwd_pass<2>(x, rowsT, ct); break;
+    case 3: zsave = bwd_pass<3>(x, rowsT, ct); break;
+    case 4: zsave = bwd_pass<4>(x, rowsT, ct); break;
+    case 5: zsave = bwd_pass<5>(x, rowsT, ct); break;
+    case 6: zsave = bwd_pass<6>(x, rowsT, ct); break;
+    default: zsave = bwd_pass<7>(x, rowsT, ct); break;
+    }
+    if (first) misc[1] = zsave;
+    const int fork0 = nfl + lo * m;
+    switch (nq) {
+    case 2: fwd_pass<2>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
+    case 3: fwd_pass<3>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
+    case 4: fwd_pass<4>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
+    case 5: fwd_pass<5>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
+    case 6: fwd_pass<6>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
+    default: fwd_pass<7>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
+    }
+    wave_lds_sync();
+    // ---- assemble S[lo + k] (fields re-read from the kernarg segment: nothing was kept live) -----
+    KArgsKernarg ap2 = ap;
+    asm volatile("" : "+s"(ap2));
+    if (act) {
+        const int zfree = misc[1] - g * ndb;
+        int32_t* const out = ap2->table + ap2->tab_off[r] + k0;
+        for (int k = lig; k < n; k += G) {
+            const int R = nfl + (lo + k) * m;
+            int sc = comb[k] - g * (R + nfr + ndb);
+            if (cEnd) sc = max(sc, lmaxA[k] - g * ndb);
+            if (cBeg) sc = max(sc, zfree);
+            comb[k] = sc;
+            out[k] = sc;
+        }
+    }
+    wave_lds_sync();
+    // ---- speculative search for start == est_cn (the no-feedback guess), replayed from LDS --------
+    int4* const spec = ap2->spec;
+    if (spec && act && first && k0 == 0) {
+        SeenMask64 seen;
+        const SearchResult res = search_replay(ap2->est_cn[r], ap2->step, ap2->lsr, ap2->max_iters, ap2->tie_last, comb, lo, n, seen);
+        spec[r] = make_int4(res.cn, res.score, res.n_explored, (res.miss ? kSpecMiss : 0) | (res.empty ? kSpecEmpty : 0));
+    }
+    wave_lds_sync();
+}
+static_assert(kCLMax == 28, "dp_wave dispatches CL/4 = 2..7");
 
-        // =============================== backward pass over fr ================================
-        // slot s holds node j = s (db chars s.. remain), s < ndb; slots >= ndb are inert pads that
-        // carry the boundary value.  Rows k' = 1..nfr consume fr[nfr-k'].
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            unsigned v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) v |= sel_of(act ? lig * CL + 4 * q + b : -1) << (8 * b);
-            sel[q] = v;
+// All fast classes in ONE launch: every wave pulls chunks (one item per group) from a device-side
+// queue, most expensive classes first.
+__global__ void __launch_bounds__(256) k_dp_all(KArgs a_by_value) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * kWaveLdsBytes + kLdsSlack];
+    uint8_t* const Lw = lds + (threadIdx.x >> 6) * kWaveLdsBytes;
+    const KArgsKernarg kernarg = (KArgsKernarg)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)a_by_value;
+    for (;;) {
+        KArgsKernarg ap = kernarg;
+        asm volatile("" : "+s"(ap));
+        int32_t* const counters = ap->counters;
+        const int list_stride = ap->list_stride;
+        int c = 0;
+        if ((threadIdx.x & 63) == 0) c = atomicAdd(&counters[kCntNextChunk], 1);
+        c = __builtin_amdgcn_readfirstlane(c);
+        int cls = -1, base = 0, acc = 0;
+        for (int k = kNumClasses - 1; k >= 0; --k) {
+            const int ngw = 64 / class_G(k);
+            const int cnt = min(counters[kCntClass0 + k], list_stride);
+            const int nch = (cnt + ngw - 1) / ngw;
+            if (c < acc + nch) { cls = k; base = (c - acc) * ngw; break; }
+            acc += nch;
         }
-#pragma unroll
-        for (int c = 0; c < CL; ++c) {
-            const int s = lig * CL + c;
-            int v = 0;
-            if (s < ndb && dbEnd) v = g * (ndb - s) - (s == 0 ? g : 0);
-            H[c] = v;
-        }
-        int zsave = 0;
-        {
-            const int Tb = wave_max_over_groups<G>(rowsT > 0 ? rowsT + G - 1 : 0);
-            const int idxMax = rowsT + 2 * (G - 1) - 1;
-            int hout = H[0];
-            int edgePrev = Lanes<G>::from_right(0, hout);
-            int kq = lig - (G - 1) + 1;   // row k' this lane works on at step t = 0
-            int gk = g * kq;
-            int zmax = H[0];
-            uint2 wordNext = tbl[ct[min(lig, idxMax < 0 ? 0 : idxMax)]];
-            for (int t = 0; t < Tb; ++t) {
-                const uint2 word = wordNext;
-                {
-                    int idx = t + 1 + lig;
-                    idx = idx > idxMax ? idxMax : idx;
-                    wordNext = tbl[ct[idx < 0 ? 0 : idx]];
-                }
-                const int bnd = cEnd ? gk : 0;
-                const int edge = Lanes<G>::from_right(bnd, hout);
-                int d = edgePrev, l = edge;
-#pragma unroll
-                for (int c = CL - 1; c >= 0; --c) {
-                    const unsigned wb = __builtin_amdgcn_perm(word.y, word.x, sel[c / 4]);
-                    const int w = (int)((wb >> (8 * (c % 4))) & 0xffu);
-                    const int up = H[c];
-                    const int nh = max(max(up, l), d + w);
-                    d = up; l = nh; H[c] = nh;
-                }
-                edgePrev = edge;
-                hout = H[0];
-                if (kq == rowsT) {
-#pragma unroll
-                    for (int c = 0; c < CL; ++c) B0[c] = H[c];
-                    zsave = zmax;
-                }
-                zmax = kq <= 0 ? H[0] : max(zmax, H[0] - gk);
-                ++kq; gk += g;
-            }
-            if (rowsT == 0) {  // unreachable for fast-class items (nfr >= 1); keeps B0 defined
-#pragma unroll
-                for (int c = 0; c < CL; ++c) B0[c] = H[c];
-            }
-        }
-        if (lig == 0) misc[1] = zsave;
-
-        // =============================== forward pass over fl + motif*i_hi =====================
-        // slot 0 is an inert pad carrying the left boundary; slot s = 1..ndb holds node j = s
-        // (consumes db[s-1]); slots > ndb replicate the last column.
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            unsigned v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int s = lig * CL + 4 * q + b;
-                v |= sel_of(act && s >= 1 ? s - 1 : -1) << (8 * b);
-            }
-            sel[q] = v;
-        }
-#pragma unroll
-        for (int c = 0; c < CL; ++c) {
-            const int s = lig * CL + c;
-            H[c] = dbBeg ? g * min(s, ndb) : 0;
-        }
-        {
-            const int Tf = wave_max_over_groups<G>(nEff > 0 ? rowsP + G - 1 : 0);
-            const int idxMax = rowsP + 2 * (G - 1) - 1;
-            int hout = H[CL - 1];
-            int edgePrev = Lanes<G>::from_left(0, hout);
-            int rq = 1 - lig;          // row this lane works on at step t = 0
-            int gr = g * rq;
-            int lastmax = kNegInf;
-            int nextFork = nEff > 0 ? nfl + lo * m : 0x7fffffff;
-            int forkIdx = 0;
-            uint2 wordNext = tbl[cp[min((G - 1) - lig, idxMax < 0 ? 0 : idxMax)]];
-            for (int t = 0; t < Tf; ++t) {
-                const uint2 word = wordNext;
-                {
-                    int idx = t + 1 + (G - 1) - lig;
-                    idx = idx > idxMax ? idxMax : idx;
-                    wordNext = tbl[cp[idx < 0 ? 0 : idx]];
-                }
-                const int bnd = cBeg ? gr : 0;
-                const int edge = Lanes<G>::from_left(bnd, hout);
-                int d = edgePrev, l = edge;
-#pragma unroll
-                for (int c = 0; c < CL; ++c) {
-                    const unsigned wb = __builtin_amdgcn_perm(word.y, word.x, sel[c / 4]);
-                    const int w = (int)((wb >> (8 * (c % 4))) & 0xffu);
-                    const int up = H[c];
-                    const int nh = max(max(up, l), d + w);
-                    d = up; l = nh; H[c] = nh;
-                }
-                edgePrev = edge;
-                hout = H[CL - 1];
-                lastmax = rq <= 0 ? kNegInf : max(lastmax, hout - gr);
-                if (rq == nextFork) {
-                    int acc = kNegInf;
-#pragma unroll
-                    for (int c = 0; c < CL; ++c) acc = max(acc, H[c] + B0[c]);
-                    atomicMax(&comb[forkIdx], acc);
-                    if (lig == G - 1) lmaxA[forkIdx] = lastmax;
-                    ++forkIdx;
-                    nextFork = forkIdx < nEff ? nextFork + m : 0x7fffffff;
-                }
-                ++rq; gr += g;
-            }
-        }
-        wave_lds_sync();
-        // ---- assemble S[lo + k] ---------------------------------------------------------------
-        if (act) {
-            const int zfree = misc[1] - g * ndb;
-            for (int k = lig; k < n; k += G) {
-                const int R = nfl + (lo + k) * m;
-                int sc = comb[k] - g * (R + nfr + ndb);
-                if (cEnd) sc = max(sc, lmaxA[k] - g * ndb);
-                if (cBeg) sc = max(sc, zfree);
-                a.table[a.tab_off[r] + k0 + k] = sc;
-            }
-        }
-        wave_lds_sync();
+        if (cls < 0) break;
+        dp_wave(ap, cls, base, Lw);
     }
 }
+static_assert(class_CL(kNumClasses - 1) <= kCLMax && class_CL(5) <= kCLMax && class_CL(9) <= kCLMax, "kCLMax covers every class");
 
 // ---------------------------------------------------------------------------------------------
 // Generic kernel: one thread per (item, candidate); plain row-by-row DP with the H row in global
@@ -558,9 +676,22 @@ __global__ void k_replay(KArgs a, ReplayArgs p) {
         int start = est;
         double frac_try = frac;
         if (p.feedback) start = feedback_start(est, &frac_try);
-        SeenMask64 seen;
-        const SearchResult res = search_replay(start, p.step, p.lsr, p.max_iters, p.tie_last,
-                                               a.table + a.tab_off[r], a.win_lo[r], min(a.win_n[r], 64), seen);
+        SearchResult res;
+        bool have = false;
+        if (a.spec && start == est) {
+            // the DP kernel already replayed the search for the no-feedback guess
+            const int4 sp = a.spec[r];
+            if (!(sp.w & kSpecMiss)) {
+                res.cn = sp.x; res.score = sp.y; res.n_explored = sp.z;
+                res.miss = 0; res.empty = (sp.w & kSpecEmpty) ? 1 : 0;
+                have = true;
+            }
+        }
+        if (!have) {
+            SeenMask64 seen;
+            res = search_replay(start, p.step, p.lsr, p.max_iters, p.tie_last, a.table + a.tab_off[r], a.win_lo[r],
+                                min(a.win_n[r], 64), seen);
+        }
         if (res.miss) {
             p.need_lo[l] = res.need_lo;
             p.need_hi[l] = res.need_hi;
