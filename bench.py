@@ -118,7 +118,7 @@ def main() -> None:
              motif_off=torch.from_numpy(b.motif_off).to(dev))
     sb = _lib.StrkBatch(n_reads=b.n_reads, n_loci=b.n_loci, **{k: v.data_ptr() for k, v in t.items()})
     out = torch.zeros((4, b.n_reads), dtype=torch.int32, device=dev)  # cn | score | n_iters | start
-    gathered = torch.zeros((world, 4, b.n_reads), dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = torch.zeros((world * 4, b.n_reads), dtype=torch.int32, device=dev) if world > 1 else None
     p = make_params(window=a.window)
     st = _lib.StrkStats()
     stream = torch.cuda.current_stream(dev)

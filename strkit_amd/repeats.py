@@ -16,6 +16,21 @@ from .repeat_count_params import RepeatCountParams
 __all__ = ["get_repeat_count"]
 
 
+def _get_repeat_count(start_count: int, tr_seq: str, flank_left_seq: str, flank_right_seq: str, motif: str,
+                      max_iters: int, local_search_range: int, step_size: int,
+                      use_shortcuts: bool = False) -> tuple[tuple[int, int], int, int]:
+    """Same signature and return value as strkit_rust_ext.get_repeat_count (call site repeats.py:58-68)."""
+    ctx = _lib.default_context()
+    cn, sc, n = C.c_int32(), C.c_int32(), C.c_int32()
+    tr, fl, fr, mo = (s.encode("ascii") for s in (tr_seq, flank_left_seq, flank_right_seq, motif))
+    rc = _lib.load().strk_repeat_count(ctx.handle, start_count, tr, len(tr), fl, len(fl), fr, len(fr), mo, len(mo),
+                                       max_iters, local_search_range, step_size, C.byref(cn), C.byref(sc), C.byref(n))
+    if rc == _lib.STRK_E_EMPTY:
+        raise ValueError("max() arg is an empty sequence")
+    _lib.check(rc)
+    return (cn.value, sc.value), n.value, cn.value - start_count
+
+
 @lru_cache(maxsize=512)  # repeats.py:47
 def get_repeat_count(
     start_count: int,
@@ -26,17 +41,18 @@ def get_repeat_count(
     rc_params: RepeatCountParams,
 ) -> tuple[tuple[int, int], int, int]:
     # returns: (best size, best score), n_explored, best size - start count
-    if rc_params.method != "repalign":
-        # repeats.py:69-70 routes "comp" to strkit_rust_ext.get_repeat_count_compostr, an experimental
-        # k-mer heuristic outside the DP hot path this backend replaces.
-        raise NotImplementedError("rc_method 'comp' is not provided by the GPU backend; use 'repalign'")
-    ctx = _lib.default_context()
-    cn, sc, n = C.c_int32(), C.c_int32(), C.c_int32()
-    tr, fl, fr, mo = (s.encode("ascii") for s in (tr_seq, flank_left_seq, flank_right_seq, motif))
-    rc = _lib.load().strk_repeat_count(ctx.handle, start_count, tr, len(tr), fl, len(fl), fr, len(fr), mo, len(mo),
-                                       rc_params.max_iters, rc_params.initial_local_search_range,
-                                       rc_params.initial_step_size, C.byref(cn), C.byref(sc), C.byref(n))
-    if rc == _lib.STRK_E_EMPTY:
-        raise ValueError("max() arg is an empty sequence")
-    _lib.check(rc)
-    return (cn.value, sc.value), n.value, cn.value - start_count
+    if rc_params.method == "repalign":
+        return _get_repeat_count(
+            start_count,
+            tr_seq,
+            flank_left_seq,
+            flank_right_seq,
+            motif,
+            rc_params.max_iters,
+            rc_params.initial_local_search_range,
+            rc_params.initial_step_size,
+            use_shortcuts=False,
+        )
+    # repeats.py:69-70 routes "comp" to strkit_rust_ext.get_repeat_count_compostr, an experimental
+    # k-mer heuristic outside the DP hot path this backend replaces.
+    raise NotImplementedError("rc_method 'comp' is not provided by the GPU backend; use 'repalign'")

@@ -1,0 +1,104 @@
+"""Loci sharding over the GPUs of one node + result collection (one process per GPU).
+
+The reference shards *locus blocks* over worker processes with no communication on the hot path
+(strkit/call/loci.py:191-204 builds blocks of <= 200 loci; strkit/call/call_sample.py:103-138,414
+hands them to workers; :195-197,420 merges the per-worker results ordered by locus index).  Here
+the workers are ranks of a torch.distributed job (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in CPU tests): blocks are dealt to ranks balanced by estimated DP cells, every rank counts
+its own loci, and ONE all-gather of fixed-size per-read records (padded to the largest shard)
+gives every rank the full table, ordered by read index exactly as a 1-GPU run produces it.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import numpy as np
+
+from .synth import LocusBatch
+
+__all__ = ["BLOCK_LOCI", "deal_blocks", "select_loci", "count_loci_sharded"]
+
+BLOCK_LOCI = 200  # strkit/call/loci.py:193
+FIELDS = ("cn", "score", "n_iters", "start")
+
+
+def _block_costs(b: LocusBatch, block: int) -> np.ndarray:
+    """Estimated DP cells per block: sum over reads of |db| * (|fl| + |tr| + window + |fr|)."""
+    ndb = (b.nfl + b.ntr + b.nfr).astype(np.int64)
+    per_read = ndb * (ndb + 64)
+    csum = np.concatenate([[0], np.cumsum(per_read)])
+    n_blocks = (b.n_loci + block - 1) // block
+    cost = np.zeros(n_blocks, np.int64)
+    for k in range(n_blocks):
+        l0, l1 = k * block, min(b.n_loci, (k + 1) * block)
+        cost[k] = csum[int(b.read_off[l1])] - csum[int(b.read_off[l0])]
+    return cost
+
+
+def deal_blocks(b: LocusBatch, world: int, block: int = BLOCK_LOCI) -> list[np.ndarray]:
+    """Deterministic longest-processing-time dealing of locus blocks to `world` ranks.
+    Returns, per rank, the sorted array of locus indices it owns."""
+    cost = _block_costs(b, block)
+    order = np.argsort(-cost, kind="stable")
+    load = np.zeros(world, np.int64)
+    owner = np.zeros(len(cost), np.int64)
+    for k in order:
+        r = int(np.argmin(load))  # first minimum: deterministic
+        owner[k] = r
+        load[r] += cost[k]
+    out = []
+    for r in range(world):
+        loci = [np.arange(k * block, min(b.n_loci, (k + 1) * block)) for k in np.nonzero(owner == r)[0]]
+        out.append(np.concatenate(loci).astype(np.int64) if loci else np.zeros(0, np.int64))
+    return out
+
+
+def select_loci(b: LocusBatch, loci: np.ndarray) -> tuple[LocusBatch, np.ndarray]:
+    """Sub-batch holding `loci` (in the given order) and the global read index of each of its reads."""
+    read_idx = [np.arange(int(b.read_off[l]), int(b.read_off[l + 1])) for l in loci]
+    reads = np.concatenate(read_idx).astype(np.int64) if len(read_idx) else np.zeros(0, np.int64)
+    seqs = [b.seqs[int(b.seq_off[r]):int(b.seq_off[r + 1])] for r in reads]
+    motifs = [b.motifs[int(b.motif_off[l]):int(b.motif_off[l + 1])] for l in loci]
+    lens = (b.seq_off[reads + 1] - b.seq_off[reads]) if len(reads) else np.zeros(0, np.int64)
+    sub = LocusBatch(
+        seqs=np.concatenate(seqs).astype(np.uint8) if seqs else np.zeros(0, np.uint8),
+        seq_off=np.concatenate([[0], np.cumsum(lens)]).astype(np.int64),
+        nfl=b.nfl[reads], ntr=b.ntr[reads], nfr=b.nfr[reads], est_cn=b.est_cn[reads],
+        read_off=np.concatenate([[0], np.cumsum([len(x) for x in read_idx])]).astype(np.int32),
+        motifs=np.concatenate(motifs).astype(np.uint8) if motifs else np.zeros(0, np.uint8),
+        motif_off=np.concatenate([[0], np.cumsum([len(x) for x in motifs])]).astype(np.int32),
+        true_cn=None if b.true_cn is None else b.true_cn[reads])
+    return sub, reads
+
+
+def count_loci_sharded(b: LocusBatch, count_fn: Callable[[LocusBatch], dict], device=None,
+                       block: int = BLOCK_LOCI) -> dict:
+    """Every rank counts its own share of `b` with `count_fn` and all ranks get the full per-read
+    table (identical to a single-process `count_fn(b)`).  Needs an initialised process group;
+    `device` is where the gathered records live (the rank's GPU for nccl/RCCL, None = CPU for gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    shares = deal_blocks(b, world, block)
+    sub, reads = select_loci(b, shares[rank])
+    res = count_fn(sub) if sub.n_reads else {k: np.zeros(0, np.int32) for k in FIELDS}
+    # fixed-size records {read_idx, cn, score, n_iters, start}, padded to the largest shard
+    n_max = max(int(sum(b.read_off[l + 1] - b.read_off[l] for l in s)) for s in shares)
+    rec = np.full((5, max(n_max, 1)), -1, np.int32)
+    rec[0, :len(reads)] = reads
+    for i, k in enumerate(FIELDS):
+        rec[i + 1, :len(reads)] = res[k]
+    t = torch.from_numpy(rec)
+    if device is not None:
+        t = t.to(device)
+    gathered = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(gathered, t)  # rank w's records land in rows [5w, 5w + 5)
+    g = gathered.cpu().numpy().reshape(world, t.shape[0], t.shape[1])
+    out = {k: np.zeros(b.n_reads, np.int32) for k in FIELDS}
+    for w in range(world):
+        idx = g[w, 0]
+        ok = idx >= 0
+        for i, k in enumerate(FIELDS):
+            out[k][idx[ok]] = g[w, i + 1][ok]
+    return out

@@ -1,0 +1,169 @@
+"""CPU: the oracle (C restatement) against known answers, the pure-Python restatement and the golden
+fixtures.  PARITY UNPINNED — see oracle/strk_oracle.c: no reference test or golden vector exists for
+this path, so these known answers are derived from the recurrence itself."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import ALPHA_IUPAC, ALPHA_WC, oracle_count, oracle_table, rand_seq, random_locus
+from oracle import py_restatement as P
+from strkit_amd.synth import LocusBatch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_scoring_matrix_rules():
+    """strkit/call/align_matrix.py:15-44 + strkit/iupac.py:9-21."""
+    m = oracle.matrix()
+    idx = {c: i for i, c in enumerate("ACGTRYSWKMBDHVNX")}
+    for c, i in idx.items():
+        assert m[i, i] == 2
+    assert m[idx["A"], idx["C"]] == -7
+    for code, members in {"R": "AG", "Y": "CT", "N": "ACGT", "H": "ACT", "B": "CGT"}.items():
+        for b in "ACGT":
+            exp = 2 if b in members else -7
+            assert m[idx[code], idx[b]] == exp and m[idx[b], idx[code]] == exp
+    for b in "ACGT":  # X neither rewards nor penalises a base (docs/caller_catalog.md:48-53)
+        assert m[idx["X"], idx[b]] == 0 and m[idx[b], idx["X"]] == 0
+    assert m[idx["X"], idx["N"]] == -7 and m[idx["R"], idx["N"]] == -7  # code-vs-code stays a mismatch
+    # the reference's IUPAC table gives D the members of H (iupac.py:17; tests/test_iupac.py:8 pins {A,C,T} -> H)
+    assert np.array_equal(m[idx["D"], :4], m[idx["H"], :4]) and m[idx["D"], idx["G"]] == -7
+    assert (m[16, :] == 0).all() and (m[:, 16] == 0).all()  # parasail's implicit '*'
+    assert np.array_equal(m, np.array(P.dna_matrix, np.int8))
+    with open(os.path.join(GOLD, "dna_matrix.json")) as f:
+        assert json.load(f)["matrix"] == m.tolist()
+    assert oracle.encode("a") == oracle.encode("A") == 0 and oracle.encode("?") == 16
+
+
+def test_alignment_known_answers():
+    s = "ACGTTGCAGGCTAAGCTTAGC"
+    assert oracle.sg_align(s, s)[0] == 2 * len(s)
+    sub = s[:10] + ("A" if s[10] != "A" else "C") + s[11:]
+    assert oracle.sg_align(s, sub, flags=0)[0] == 2 * len(s) - 9          # one substitution: -2 -7
+    assert oracle.sg_align(s, s[:10] + s[11:], flags=0)[0] == 2 * (len(s) - 1) - 5   # one deleted base
+    assert oracle.sg_align(s, s[:10] + "X" + s[11:], flags=0)[0] == 2 * (len(s) - 1)  # X column scores 0
+    assert oracle.sg_align("AAGAG", "AARRG", flags=0)[0] == 10              # IUPAC motif vs a member read
+    assert oracle.sg_align("G", "D", flags=0)[0] == -7                      # the D quirk
+    # free end gaps: a short sequence inside a long one costs nothing at the ends
+    assert oracle.sg_align("TTTT" + s + "CCCC", s, flags=oracle.S1_BEG_FREE | oracle.S1_END_FREE)[0] == 2 * len(s)
+    assert oracle.sg_align("TTTT" + s + "CCCC", s, flags=0)[0] == 2 * len(s) - 5 * 8
+    assert oracle.sg_align("", "ACGT") == (0, -1, -1)
+
+
+def test_pure_tract_converges_in_nine_alignments():
+    """(i) fl + motif*n + fr from start = n: cn = n, perfect score, 7 + 1 + 1 sizes explored."""
+    fl, fr = "ACGTTGCATTGACCGTA", "GGATCCATTCGAATGCA"
+    for motif, n in (("CAG", 12), ("AT", 7), ("GGCCC", 20), ("A", 30)):
+        tr = motif * n
+        (cn, score), n_explored, delta = oracle.repeat_count(n, tr, fl, fr, motif)
+        assert (cn, score, delta) == (n, 2 * len(fl + tr + fr), 0)
+        assert n_explored == 9
+        assert P.get_repeat_count(n, tr, fl, fr, motif) == ((cn, score), n_explored, delta)
+
+
+def test_search_chases_a_distant_start_and_respects_limits():
+    fl, fr, motif = "ACGTTGCATTGACCGTA", "GGATCCATTCGAATGCA", "CAG"
+    tr = motif * 25
+    for start in (15, 35, 0, 3):
+        (cn, score), n, delta = oracle.repeat_count(start, tr, fl, fr, motif)
+        assert cn == 25 and score == 2 * len(fl + tr + fr) and delta == 25 - start
+    (cn, _), n, _ = oracle.repeat_count(10, tr, fl, fr, motif, max_iters=5)  # (v) cut-off
+    assert n >= 5 and cn < 25
+    with pytest.raises(ValueError):  # every seed negative -> nothing scored (Python max() would raise)
+        oracle.repeat_count(-5, tr, fl, fr, motif)
+    assert oracle.repeat_count(0, "", fl, fr, motif)[0][0] == 0
+
+
+def test_partial_copy_rounds_up_under_alignment_scoring():
+    """Motif AC, 31-base tract ACAC...A (the shape of the docs example, docs/output_formats.md:92-104,
+    which was produced with rc_method "comp" and reports read cn 15): under the repalign scoring a
+    16th copy costs one gap but wins one more match than 15 copies, so the aligner's answer is 16."""
+    tr = ("AC" * 16)[:31]
+    fl, fr = "GATTACAGATTACAGGT", "TTGGCCATAGCTAGGCT"
+    (cn, score), _, _ = oracle.repeat_count(round(31 / 2), tr, fl, fr, "AC")
+    assert cn == 16 and score == 2 * (len(fl) + 31 + len(fr)) - 5
+    assert oracle.candidate_score(tr, fl, fr, "AC", 15) == 2 * (len(fl) + 30 + len(fr)) - 5
+
+
+def test_tie_rules_differ_only_on_ties():
+    rng = np.random.default_rng(5)
+    seen_diff = False
+    for _ in range(300):
+        motif, reads = random_locus(rng, 1, motif_len=(1, 3), cn=(0, 6), flank=(1, 6), edits=(0, 3))
+        fl, tr, fr = reads[0]
+        a = oracle.repeat_count(2, tr, fl, fr, motif, tie_rule=oracle.TIE_FIRST)
+        b = oracle.repeat_count(2, tr, fl, fr, motif, tie_rule=oracle.TIE_LAST)
+        assert a[0][1] == b[0][1] or a[1] != b[1]  # same best score unless the explored sets diverged
+        seen_diff |= a != b
+        assert P.get_repeat_count(2, tr, fl, fr, motif) == a
+        assert P.get_repeat_count(2, tr, fl, fr, motif, tie_last=True) == b
+    assert seen_diff
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_c_oracle_matches_python_restatement(seed):
+    rng = np.random.default_rng(seed)
+    for _ in range(150):
+        a, b = rand_seq(rng, int(rng.integers(0, 25)), ALPHA_IUPAC), rand_seq(rng, int(rng.integers(0, 25)), ALPHA_IUPAC)
+        flags = int(rng.integers(0, 16))
+        got = oracle.sg_align(a, b, 5, 5, flags)
+        if not a or not b:
+            assert got[0] == 0
+            continue
+        exp = P.sg_align(a, b, 5, 5, bool(flags & 1), bool(flags & 2), bool(flags & 4), bool(flags & 8))
+        assert got[0] == exp[0], (a, b, flags)
+    for _ in range(40):
+        motif, reads = random_locus(rng, 4, cn=(0, 12), flank=(3, 20), alpha=ALPHA_WC, motif_alpha=ALPHA_IUPAC)
+        b = LocusBatch.from_reads([(motif, reads)])
+        b.est_cn = np.maximum(0, b.est_cn + rng.integers(-5, 6, size=b.n_reads)).astype(np.int32)
+        exp = P.count_locus(reads, motif, [int(x) for x in b.est_cn])
+        got = oracle_count(b)
+        assert [tuple(int(got[k][i]) for k in ("cn", "score", "n_iters", "start")) for i in range(b.n_reads)] == exp
+
+
+def test_reference_side_matches_python_restatement():
+    """get_ref_repeat_count / score_ref_boundaries (strkit/call/repeats.py:23-43,73-192)."""
+    rng = np.random.default_rng(9)
+    for _ in range(60):
+        motif = rand_seq(rng, int(rng.integers(1, 6)))
+        cn = int(rng.integers(2, 12))
+        ext_l, ext_r = int(rng.integers(0, 3)), int(rng.integers(0, 3))  # repeat copies hidden in the flanks
+        fl = rand_seq(rng, 25) + motif * ext_l
+        fr = motif * ext_r + rand_seq(rng, 25)
+        tr = motif * cn
+        ref_size = len(tr)
+        args = (cn, tr, fl, fr, motif, ref_size, 5, 50, 3, 1)
+        assert oracle.ref_repeat_count(*args) == P.get_ref_repeat_count(*args)
+        db = fl + tr + fr
+        assert oracle.score_ref_boundaries(db, fl, fr, motif, cn, ref_size) == \
+            P.score_ref_boundaries(db, motif * cn, fl, fr, ref_size)
+        assert oracle.ref_repeat_count(*args, respect_coords=True) == P.get_ref_repeat_count(*args, respect_coords=True)
+
+
+def _golden_batch(loci_json):
+    b = LocusBatch.from_reads([(l["motif"], [tuple(r) for r in l["reads"]]) for l in loci_json],
+                              [l["est_cn"] for l in loci_json])
+    return b
+
+
+def test_golden_count_cases():
+    with open(os.path.join(GOLD, "count_cases.json")) as f:
+        cases = json.load(f)
+    assert set(cases) >= {"cfg1_hifi", "cfg3_ont", "cfg5_long", "adversarial_first_max", "adversarial_last_max"}
+    for name, case in cases.items():
+        b = _golden_batch(case["loci"])
+        got = oracle_count(b, **case.get("params", {}))
+        for k, v in case["expected"].items():
+            assert got[k].tolist() == v, (name, k)
+
+
+def test_golden_score_tables():
+    with open(os.path.join(GOLD, "score_tables.json")) as f:
+        g = json.load(f)
+    b = _golden_batch(g["loci"])
+    for flags, tabs in g["tables"].items():
+        got = oracle_table(b, g["lo"], g["n"], int(flags))
+        assert [t.tolist() for t in got] == tabs, flags
