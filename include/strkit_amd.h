@@ -11,10 +11,11 @@
  *                            read with the running start-count feedback
  *                            — strkit/call/call_locus.py:1082,1125-1161; sharded over workers at
  *                            strkit/call/call_sample.py:103-138,414
+ *   strk_submit_loci_device / strk_finish   the same loop, split so that successive blocks of loci
+ *                            overlap on the device (the reference overlaps them across its worker
+ *                            processes, strkit/call/call_sample.py:414)
  *   strk_score_table         one parasail semi-global alignment score per candidate copy number
  *                            (the innermost operation; shape of strkit/call/repeats.py:33,40,124)
- *   strk_ref_repeat_count    get_ref_repeat_count() incl. score_ref_boundaries()
- *                            — strkit/call/repeats.py:23-43,73-192 (parasail sg_qe_scan_profile_sat)
  *
  * Conventions: plain pointers and sizes, caller-owned buffers, no allocation crosses the ABI
  * except the opaque context.  Every function returns 0 on success or a negative STRK_E_* code;
@@ -122,6 +123,15 @@ int strk_count_loci(strk_ctx* ctx, const strk_batch* batch, const strk_params* p
 int strk_count_loci_device(strk_ctx* ctx, const strk_batch* batch, const strk_params* params,
                            int32_t* out_cn, int32_t* out_score, int32_t* out_n_iters,
                            int32_t* out_start, void* stream, strk_stats* stats);
+
+/* Pipelined form of strk_count_loci_device: strk_submit_loci_device enqueues the whole call on
+ * `stream` and returns at once; strk_finish waits for it, resolves window misses and fills `stats`.
+ * One call may be in flight per context (use one context per stream to overlap batches); every
+ * pointer inside `batch` and every out_* pointer must stay valid until strk_finish returns. */
+int strk_submit_loci_device(strk_ctx* ctx, const strk_batch* batch, const strk_params* params,
+                            int32_t* out_cn, int32_t* out_score, int32_t* out_n_iters,
+                            int32_t* out_start, void* stream);
+int strk_finish(strk_ctx* ctx, strk_stats* stats);
 
 /* Parity primitive: scores[table_off[r] + k] = semi-global score of (fl + motif*(lo[r]+k) + fr)
  * against (fl+tr+fr) for k < n[r].  HOST buffers.  table_off is [n_reads + 1]. */

@@ -43,7 +43,7 @@ class StrkStats(C.Structure):
 
 # Every symbol include/strkit_amd.h declares (tests check the .so exports exactly these).
 EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_repeat_count", "strk_count_loci",
-           "strk_count_loci_device", "strk_score_table")
+           "strk_count_loci_device", "strk_submit_loci_device", "strk_finish", "strk_score_table")
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -89,6 +89,11 @@ def load(build: bool = True):
         L.strk_count_loci_device.restype = C.c_int
         L.strk_count_loci_device.argtypes = ([C.c_void_p, C.POINTER(StrkBatch), C.POINTER(StrkParams)]
                                              + [C.c_void_p] * 4 + [C.c_void_p, C.POINTER(StrkStats)])
+        L.strk_submit_loci_device.restype = C.c_int
+        L.strk_submit_loci_device.argtypes = ([C.c_void_p, C.POINTER(StrkBatch), C.POINTER(StrkParams)]
+                                              + [C.c_void_p] * 4 + [C.c_void_p])
+        L.strk_finish.restype = C.c_int
+        L.strk_finish.argtypes = [C.c_void_p, C.POINTER(StrkStats)]
         L.strk_score_table.restype = C.c_int
         L.strk_score_table.argtypes = [C.c_void_p, C.POINTER(StrkBatch), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int32, C.c_int32, C.c_void_p, C.POINTER(StrkStats)]

@@ -76,6 +76,13 @@ struct strk_ctx {
     int32_t* h_counters = nullptr;  // pinned: counters + cells + scratch_used
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_ints = 0;
+    // one submitted-but-not-finished batched call (strk_submit_loci_device .. strk_finish)
+    bool pending = false;
+    strk_batch p_batch;
+    strk_params p_params;
+    strk::KArgs p_args;
+    strk::ReplayArgs p_replay;
+    hipStream_t p_stream = nullptr;
 };
 
 namespace {
@@ -181,7 +188,7 @@ struct SeenVec {
 // Host-driven rounds for loci whose search left the speculative window.  Everything here works on
 // DEVICE batch pointers; host copies of the small metadata are fetched once.
 int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs a, ReplayArgs rp, hipStream_t st,
-                   strk_stats* stats) {
+                   strk_stats* stats, int err_bits) {
     const int nr = b->n_reads, nl = b->n_loci;
     std::vector<int32_t> read_off(nl + 1), est(nr), win_lo(nr), win_n(nr), next_read(nl), need_lo(nl), need_hi(nl);
     std::vector<int64_t> tab_off(nr);
@@ -320,17 +327,24 @@ int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs
         stats->n_miss_reads = miss_reads;
         stats->n_miss_rounds = rounds;
     }
-    return check_error_bits(c->h_counters[kCntError]);
+    return check_error_bits(c->h_counters[kCntError] | err_bits);
 }
 
-int count_device(strk_ctx* c, const strk_batch* b, const strk_params* params, int32_t* out_cn, int32_t* out_score,
-                 int32_t* out_n, int32_t* out_start, hipStream_t st, strk_stats* stats) {
+// Enqueue one batched call on `st` and return without waiting.
+int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, int32_t* out_cn, int32_t* out_score,
+                  int32_t* out_n, int32_t* out_start, hipStream_t st) {
+    if (c->pending) return fail(STRK_E_INVALID, "context already holds a submitted call: strk_finish() it first");
     strk_params p;
     int rc;
     if ((rc = check_params(params, &p))) return rc;
-    if (stats) memset(stats, 0, sizeof *stats);
     if (!b || b->n_reads < 0 || b->n_loci < 0) return fail(STRK_E_INVALID, "bad batch");
-    if (b->n_reads == 0 || b->n_loci == 0) return 0;
+    c->p_batch = *b;
+    c->p_params = p;
+    c->p_stream = st;
+    if (b->n_reads == 0 || b->n_loci == 0) {
+        c->pending = true;
+        return 0;
+    }
     if (!out_cn || !out_score || !out_n || !out_start) return fail(STRK_E_INVALID, "output pointer is NULL");
     HIP_TRY(hipSetDevice(c->device));
     const int ts = 2 * p.window + 1;
@@ -348,10 +362,25 @@ int count_device(strk_ctx* c, const strk_batch* b, const strk_params* params, in
     HIP_TRY(hipEventRecord(c->ev[0], st));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
     enqueue_scoring(c, a, 0, nullptr, b->n_reads, 0, st, true);
-    hipLaunchKernelGGL(k_replay, dim3((b->n_loci + 63) / 64), dim3(64), 0, st, a, rp);
+    hipLaunchKernelGGL(k_replay, dim3(b->n_loci), dim3(64), 0, st, a, rp);
     HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(c->ev[3], st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    c->p_args = a;
+    c->p_replay = rp;
+    c->pending = true;
+    return 0;
+}
+
+// Wait for the submitted call, check for errors and resolve window misses.
+int finish_device(strk_ctx* c, strk_stats* stats) {
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!c->pending) return fail(STRK_E_INVALID, "nothing was submitted on this context");
+    c->pending = false;
+    const strk_batch* b = &c->p_batch;
+    if (b->n_reads == 0 || b->n_loci == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[3]));
     HIP_TRY(hipGetLastError());
     if (stats) {
         float ms = 0.f;
@@ -362,9 +391,18 @@ int count_device(strk_ctx* c, const strk_batch* b, const strk_params* params, in
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
     }
     const int err = c->h_counters[kCntError];
+    int rc;
     if ((rc = check_error_bits(err & ~kErrEmpty))) return rc;
-    if (c->h_counters[kCntMiss] > 0) return resolve_misses(c, b, p, a, rp, st, stats);
+    if (c->h_counters[kCntMiss] > 0) return resolve_misses(c, b, c->p_params, c->p_args, c->p_replay, c->p_stream, stats, err);
     return check_error_bits(err);
+}
+
+int count_device(strk_ctx* c, const strk_batch* b, const strk_params* params, int32_t* out_cn, int32_t* out_score,
+                 int32_t* out_n, int32_t* out_start, hipStream_t st, strk_stats* stats) {
+    if (stats) memset(stats, 0, sizeof *stats);
+    const int rc = submit_device(c, b, params, out_cn, out_score, out_n, out_start, st);
+    if (rc) return rc;
+    return finish_device(c, stats);
 }
 
 // uploads a host batch into the context's staging buffers; returns a batch of device pointers
@@ -466,6 +504,17 @@ int strk_count_loci_device(strk_ctx* ctx, const strk_batch* batch, const strk_pa
                            strk_stats* stats) {
     if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
     return count_device(ctx, batch, params, out_cn, out_score, out_n_iters, out_start, static_cast<hipStream_t>(stream), stats);
+}
+
+int strk_submit_loci_device(strk_ctx* ctx, const strk_batch* batch, const strk_params* params, int32_t* out_cn,
+                            int32_t* out_score, int32_t* out_n_iters, int32_t* out_start, void* stream) {
+    if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
+    return submit_device(ctx, batch, params, out_cn, out_score, out_n_iters, out_start, static_cast<hipStream_t>(stream));
+}
+
+int strk_finish(strk_ctx* ctx, strk_stats* stats) {
+    if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
+    return finish_device(ctx, stats);
 }
 
 int strk_count_loci(strk_ctx* ctx, const strk_batch* batch, const strk_params* params, int32_t* out_cn,

@@ -29,6 +29,7 @@ namespace strk {
 
 constexpr int kTableMax = 32;       // max candidates per read in one DP item
 constexpr int kNegInf = -(1 << 29);
+constexpr int kMotifMax = 256;     // the fast kernel stages the encoded motif in LDS (<= 2 * smallest capacity bytes)
 constexpr int kRowSlack = 160;      // a class of capacity CAP accepts up to CAP + kRowSlack prefix rows
 
 // Fast-kernel classes: (G lanes per read, CL columns per lane); capacity = G*CL slots >= |db| + 1.
@@ -94,7 +95,7 @@ constexpr int kSpecMiss = 1, kSpecEmpty = 2;
 __device__ inline int classify(int nfl, int ntr, int nfr, int m, int lo, int n, int force_generic) {
     const long long ndb = (long long)nfl + ntr + nfr;
     const long long rows = (long long)nfl + (long long)(lo + n - 1) * m;
-    if (force_generic || nfl < 1 || nfr < 1 || n > kTableMax) return kGenericClass;
+    if (force_generic || nfl < 1 || nfr < 1 || n > kTableMax || m > kMotifMax) return kGenericClass;
     for (int c = 0; c < kNumClasses; ++c) {
         const int cap = class_cap(c);
         if (ndb + 1 <= cap && rows <= cap + kRowSlack) return c;
@@ -382,7 +383,8 @@ __device__ __forceinline__ void fwd_pass(const PassCtx& x, int rowsP, const uint
 // epilogue are one body, only the two hot loops are specialised on CL/4 (six copies each).
 // `ap` points at the kernel's KArgs in the kernarg segment: fields are scalar-loaded where they are
 // used instead of living in SGPRs across the hot loops.
-__device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint8_t* Lw) {
+__device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint8_t* Lw, const uint8_t* s_enc,
+                                        const int8_t* s_mat) {
     constexpr int g = kGap;
     const int G = class_G(cls), CL = class_CL(cls), nq = CL / 4;
     const DpLayout lay(G, CL);
@@ -427,21 +429,33 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     const int rowsT = act ? nfr : 0;
 
     // ---- stage the encoded read window and collect its symbol set ------------------------------
+    uint8_t* const motifL = Lg + lay.off_b0;   // encoded motif; the area is free until the backward pass ends
     if (first) misc[0] = 0;
     wave_lds_sync();
     {
         unsigned mask = 0;
         const uint8_t* seq = ap->seqs + soff;
-        for (int s = lig; s < lay.cap + 8; s += G) {
-            int sym = 0xff;
-            const int j = s - 4;
-            if (act && j >= 0 && j < ndb) {
-                sym = c_enc[seq[j]];
-                mask |= 1u << sym;
+        const int total = lay.cap + 8;
+        for (int s0 = lig; s0 < total; s0 += 4 * G) {   // four independent loads in flight per lane
+            int raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = s0 + u * G - 4;
+                raw[u] = (act && j >= 0 && j < ndb) ? (int)seq[j] : -1;
             }
-            dbs[s] = (uint8_t)sym;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = s0 + u * G;
+                int sym = 0xff;
+                if (raw[u] >= 0) {
+                    sym = s_enc[raw[u]];
+                    mask |= 1u << sym;
+                }
+                if (s < total) dbs[s] = (uint8_t)sym;
+            }
         }
         if (mask) atomicOr(reinterpret_cast<unsigned*>(&misc[0]), mask);
+        for (int k = lig; k < m; k += G) motifL[k] = act ? s_enc[motif[k]] : (uint8_t)kNullSym;
     }
     wave_lds_sync();
     const unsigned symmask = (unsigned)misc[0];
@@ -470,7 +484,7 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
             for (int s = 0; s < kNSym; ++s) {
                 if (!((symmask >> s) & 1u)) continue;
                 if (k < 8) {
-                    const unsigned b = (unsigned)(c_mat[e][s] + kWBias) & 0xffu;
+                    const unsigned b = (unsigned)(s_mat[e * kNSym + s] + kWBias) & 0xffu;
                     if (k < 4) wlo |= b << (8 * k); else whi |= b << (8 * (k - 4));
                 }
                 ++k;
@@ -482,11 +496,16 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     // ---- candidate row symbols: null padding | fl | motif*i_hi | null padding ------------------
     {
         const int lenP = rowsP + 2 * (G - 1) + 4;
+        const int gstep = G % m;
+        int ph = (lig - (G - 1) - nfl) % m;   // phase of this lane's first row inside the motif
+        if (ph < 0) ph += m;
         for (int idx = lig; idx < lenP; idx += G) {
             const int row = idx - (G - 1);  // 0-based row
             int sym = kNullSym;
-            if (row >= 0 && row < rowsP) sym = row < nfl ? dbs[4 + row] : c_enc[motif[(row - nfl) % m]];
+            if (row >= 0 && row < rowsP) sym = row < nfl ? dbs[4 + row] : motifL[ph];
             cp[idx] = (uint8_t)sym;
+            ph += gstep;
+            if (ph >= m) ph -= m;
         }
         const int lenT = rowsT + 2 * (G - 1) + 4;
         for (int idx = lig; idx < lenT; idx += G) {
@@ -498,9 +517,18 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     }
     wave_lds_sync();
     // ---- db symbols -> v_perm selector bytes (class id = rank of the symbol's bit; pads -> 0x0c = constant 0)
-    for (int s = lig; s < lay.cap + 8; s += G) {
-        const unsigned sym = dbs[s];
-        dbs[s] = (uint8_t)(sym < (unsigned)kNSym ? __popc(symmask & ((1u << sym) - 1u)) : 0x0c);
+    {
+        unsigned* const dbw = reinterpret_cast<unsigned*>(dbs);
+        for (int wi = lig; wi < (lay.cap + 8) / 4; wi += G) {
+            const unsigned v = dbw[wi];
+            unsigned o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned sym = (v >> (8 * b)) & 0xffu;
+                o |= (sym < (unsigned)kNSym ? (unsigned)__popc(symmask & ((1u << sym) - 1u)) : 0x0cu) << (8 * b);
+            }
+            dbw[wi] = o;
+        }
     }
     wave_lds_sync();
 
@@ -562,6 +590,11 @@ static_assert(kCLMax == 28, "dp_wave dispatches CL/4 = 2..7");
 // queue, most expensive classes first.
 __global__ void __launch_bounds__(256) k_dp_all(KArgs a_by_value) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * kWaveLdsBytes + kLdsSlack];
+    __shared__ uint8_t s_enc[256];
+    __shared__ int8_t s_mat[kNSym * kNSym + 3];
+    s_enc[threadIdx.x] = c_enc[threadIdx.x];
+    for (int i = threadIdx.x; i < kNSym * kNSym; i += 256) s_mat[i] = c_mat[i / kNSym][i % kNSym];
+    __syncthreads();
     uint8_t* const Lw = lds + (threadIdx.x >> 6) * kWaveLdsBytes;
     const KArgsKernarg kernarg = (KArgsKernarg)__builtin_amdgcn_kernarg_segment_ptr();
     (void)a_by_value;
@@ -582,7 +615,7 @@ __global__ void __launch_bounds__(256) k_dp_all(KArgs a_by_value) {
             acc += nch;
         }
         if (cls < 0) break;
-        dp_wave(ap, cls, base, Lw);
+        dp_wave(ap, cls, base, Lw, s_enc, s_mat);
     }
 }
 static_assert(class_CL(kNumClasses - 1) <= kCLMax && class_CL(5) <= kCLMax && class_CL(9) <= kCLMax, "kCLMax covers every class");
@@ -665,53 +698,74 @@ struct ReplayArgs {
     int32_t* need_hi;
 };
 
-__global__ void k_replay(KArgs a, ReplayArgs p) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= a.n_loci) return;
+// One wave per locus: lane i holds the inputs of the locus's i-th read (coalesced loads), the
+// in-order chain over the reads is wave-uniform ALU work on values fetched with v_readlane.
+__global__ void __launch_bounds__(64) k_replay(KArgs a, ReplayArgs p) {
+    const int l = blockIdx.x;
+    const int lane = threadIdx.x;
     const int r_end = a.read_off[l + 1];
     double frac = 0.0;
-    int r = a.read_off[l];
-    for (; r < r_end; ++r) {
-        const int est = a.est_cn[r];
-        int start = est;
-        double frac_try = frac;
-        if (p.feedback) start = feedback_start(est, &frac_try);
-        SearchResult res;
-        bool have = false;
-        if (a.spec && start == est) {
-            // the DP kernel already replayed the search for the no-feedback guess
-            const int4 sp = a.spec[r];
-            if (!(sp.w & kSpecMiss)) {
-                res.cn = sp.x; res.score = sp.y; res.n_explored = sp.z;
-                res.miss = 0; res.empty = (sp.w & kSpecEmpty) ? 1 : 0;
-                have = true;
+    int r_next = a.read_off[l];   // first read not finished yet
+    bool missed = false;
+    for (int base = r_next; base < r_end && !missed; base += 64) {
+        const int cnt = min(64, r_end - base);
+        const int rl = base + lane;
+        const int my_est = lane < cnt ? a.est_cn[rl] : 0;
+        int4 my_spec = make_int4(0, 0, 0, kSpecMiss);
+        if (a.spec && lane < cnt) my_spec = a.spec[rl];
+        int o_cn = 0, o_score = 0, o_n = 0, o_start = 0;
+        int done = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const int est = __builtin_amdgcn_readlane(my_est, i);
+            int start = est;
+            double frac_try = frac;
+            if (p.feedback) start = feedback_start(est, &frac_try);
+            SearchResult res;
+            const int spec_flags = __builtin_amdgcn_readlane(my_spec.w, i);
+            if (start == est && !(spec_flags & kSpecMiss)) {
+                // the DP kernel already replayed the search for the no-feedback guess
+                res.cn = __builtin_amdgcn_readlane(my_spec.x, i);
+                res.score = __builtin_amdgcn_readlane(my_spec.y, i);
+                res.n_explored = __builtin_amdgcn_readlane(my_spec.z, i);
+                res.miss = 0;
+                res.empty = (spec_flags & kSpecEmpty) ? 1 : 0;
+            } else {
+                const int r = base + i;
+                SeenMask64 seen;
+                res = search_replay(start, p.step, p.lsr, p.max_iters, p.tie_last, a.table + a.tab_off[r], a.win_lo[r],
+                                    min(a.win_n[r], 64), seen);
             }
+            if (res.miss) {
+                if (lane == 0) {
+                    p.need_lo[l] = res.need_lo;
+                    p.need_hi[l] = res.need_hi;
+                    atomicAdd(&a.counters[kCntMiss], 1);
+                }
+                missed = true;
+                break;
+            }
+            frac = frac_try;
+            if (res.empty) {
+                if (lane == 0) atomicOr(&a.counters[kCntError], kErrEmpty);  // the reference would raise here
+                res.cn = 0;
+                res.score = 0;
+            }
+            if (lane == i) { o_cn = res.cn; o_score = res.score; o_n = res.n_explored; o_start = start; }
+            if (p.feedback && !res.empty && res.cn != start) feedback_update(&frac, res.cn, start);  // += 0 otherwise
+            done = i + 1;
         }
-        if (!have) {
-            SeenMask64 seen;
-            res = search_replay(start, p.step, p.lsr, p.max_iters, p.tie_last, a.table + a.tab_off[r], a.win_lo[r],
-                                min(a.win_n[r], 64), seen);
+        if (lane < done) {
+            p.out_cn[rl] = o_cn;
+            p.out_score[rl] = o_score;
+            p.out_n[rl] = o_n;
+            p.out_start[rl] = o_start;
         }
-        if (res.miss) {
-            p.need_lo[l] = res.need_lo;
-            p.need_hi[l] = res.need_hi;
-            atomicAdd(&a.counters[kCntMiss], 1);
-            break;
-        }
-        frac = frac_try;
-        if (res.empty) {
-            atomicOr(&a.counters[kCntError], kErrEmpty);
-            p.out_cn[r] = 0; p.out_score[r] = 0; p.out_n[r] = res.n_explored; p.out_start[r] = start;
-            continue;  // the reference would raise here; the host turns the flag into an error
-        }
-        p.out_cn[r] = res.cn;
-        p.out_score[r] = res.score;
-        p.out_n[r] = res.n_explored;
-        p.out_start[r] = start;
-        if (p.feedback) feedback_update(&frac, res.cn, start);
+        r_next = base + done;
     }
-    p.next_read[l] = r;
-    p.frac[l] = frac;
+    if (lane == 0) {
+        p.next_read[l] = r_next;
+        p.frac[l] = frac;
+    }
 }
 
 }  // namespace strk
