@@ -80,7 +80,8 @@ def main() -> None:
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's own count)")
     ap.add_argument("--window", type=int, default=0)
-    ap.add_argument("--pipeline", type=int, default=2, help="batched calls in flight (contexts/streams)")
+    ap.add_argument("--no-dedupe", action="store_true", help="score identical reads of a locus separately")
+    ap.add_argument("--pipeline", type=int, default=3, help="batched calls in flight (contexts/streams)")
     ap.add_argument("--cpu-sample-loci", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -117,7 +118,7 @@ def main() -> None:
              read_off=torch.from_numpy(b.read_off).to(dev), motifs=torch.from_numpy(b.motifs).to(dev),
              motif_off=torch.from_numpy(b.motif_off).to(dev))
     sb = _lib.StrkBatch(n_reads=b.n_reads, n_loci=b.n_loci, **{k: v.data_ptr() for k, v in t.items()})
-    p = make_params(window=a.window)
+    p = make_params(window=a.window, dedupe=not a.no_dedupe)
     st = _lib.StrkStats()
     # D steps in flight: one context (workspace) + one HIP stream + one output buffer per slot, so
     # the tail of one batch overlaps the head of the next (successive locus blocks of a real run).
@@ -126,7 +127,7 @@ def main() -> None:
     streams = [torch.cuda.Stream(dev) for _ in range(D)]
     outs = [torch.zeros((4, b.n_reads), dtype=torch.int32, device=dev) for _ in range(D)]  # cn | score | n_iters | start
     gathered = [torch.zeros((world * 4, b.n_reads), dtype=torch.int32, device=dev) for _ in range(D)] if world > 1 else None
-    acc = dict(dp_ms=0.0, all_ms=0.0, misses=0, fallback=0, n=0)
+    acc = dict(dp_ms=0.0, all_ms=0.0, misses=0, fallback=0, dedup=0, n=0)
 
     def submit(i):
         k = i % D
@@ -141,7 +142,8 @@ def main() -> None:
         _lib.check(L.strk_finish(ctxs[k].handle, C.byref(st)))
         if timed:
             acc["dp_ms"] += st.dp_kernel_ms; acc["all_ms"] += st.kernel_ms
-            acc["misses"] += st.n_miss_reads; acc["fallback"] += st.n_fallback; acc["n"] += 1
+            acc["misses"] += st.n_miss_reads; acc["fallback"] += st.n_fallback; acc["dedup"] += st.n_dedup_reads
+            acc["n"] += 1
         if world > 1:  # collect per-read results of every shard (RCCL all-gather over xGMI)
             dist.all_gather_into_tensor(gathered[k], outs[k])
 
@@ -219,6 +221,7 @@ def main() -> None:
                      "peak_int32_tops": VALU_PEAK_TOPS, "unit": "G cell updates/s"},
             "device_ms_per_step": all_ms / a.steps, "isolated_call": {"dp_kernel_ms": iso_dp, "device_ms": iso_all}, "window_miss_reads_per_step": misses / a.steps,
             "generic_kernel_items_per_step": fallback / a.steps,
+            "dedup_reads_per_step": acc["dedup"] / a.steps, "dedupe": not a.no_dedupe,
             "parity_check": parity,
             "cpu_baseline": cpu,
         }

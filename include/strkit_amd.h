@@ -66,7 +66,9 @@ typedef struct strk_params {
     int32_t feedback;           /* 1: start-count feedback across the reads of a locus
                                    (call_locus.py:1129-1136,1161); 0: start = est_cn as given */
     int32_t window;             /* half-width of the speculative score table per read; 0 = default */
-    int32_t reserved;
+    int32_t no_dedupe;          /* 0 (default): reads of a locus with identical bytes, split and estimate
+                                   share one score table (the reference's lru_cache, repeats.py:47);
+                                   1: score every read separately */
 } strk_params;
 
 /* CSR-packed batch of loci.  Read r owns seqs[seq_off[r] .. seq_off[r+1]) laid out fl|tr|fr;
@@ -96,7 +98,7 @@ typedef struct strk_stats {
     float kernel_ms;       /* HIP-event time of the device work of this call */
     float dp_kernel_ms;    /* ... of the DP kernels alone */
     int32_t n_dp_launches;
-    int32_t reserved;
+    int32_t n_dedup_reads; /* reads served by the score table of an identical earlier read */
 } strk_stats;
 
 int strk_init(int device, strk_ctx** out);

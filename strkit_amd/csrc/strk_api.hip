@@ -68,7 +68,7 @@ struct DevBuf {
 struct strk_ctx {
     int device = 0;
     // workspace
-    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, counters, scratch, state_i32, state_f64, spec;
+    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, counters, scratch, state_i32, state_f64, spec, rhash, rep;
     DevBuf win_lo2, win_n2, tab_off2, table2, items;
     // staging for the host-buffer entry points
     DevBuf in_seqs, in_seq_off, in_nfl, in_ntr, in_nfr, in_est, in_read_off, in_motifs, in_motif_off;
@@ -121,6 +121,8 @@ int ensure_workspace(strk_ctx* c, int n_reads, int n_loci, size_t table_ints, si
     if ((rc = c->state_i32.ensure(nl * 3 * 4))) return rc;
     if ((rc = c->state_f64.ensure(nl * 8))) return rc;
     if ((rc = c->spec.ensure(nr * 16))) return rc;
+    if ((rc = c->rhash.ensure(nr * 8))) return rc;
+    if ((rc = c->rep.ensure(nr * 4))) return rc;
     if (!c->scratch.p) {
         if ((rc = c->scratch.ensure(kScratchInts * 4))) return rc;
         c->scratch_ints = kScratchInts;
@@ -154,6 +156,8 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
         a.spec = static_cast<int4*>(c->spec.p);
         a.max_iters = sp->max_iters; a.lsr = sp->local_search_range; a.step = sp->step_size;
         a.tie_last = sp->tie_rule == STRK_TIE_LAST;
+        a.rep = c->rep.as<int32_t>();
+        a.rhash = sp->no_dedupe ? nullptr : c->rhash.as<unsigned long long>();
     }
     return a;
 }
@@ -361,6 +365,7 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
 
     HIP_TRY(hipEventRecord(c->ev[0], st));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
+    if (a.rhash) hipLaunchKernelGGL(k_hash, dim3((b->n_reads + 255) / 256), dim3(256), 0, st, a);
     enqueue_scoring(c, a, 0, nullptr, b->n_reads, 0, st, true);
     hipLaunchKernelGGL(k_replay, dim3(b->n_loci), dim3(64), 0, st, a, rp);
     HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
@@ -388,6 +393,7 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) stats->dp_kernel_ms = ms;
         stats->n_dp_launches = 2;
         stats->n_fallback = c->h_counters[kCntClass0 + kGenericClass];
+        stats->n_dedup_reads = c->h_counters[kCntDup];
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
     }
     const int err = c->h_counters[kCntError];
@@ -488,7 +494,7 @@ void strk_destroy(strk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->read_locus, &c->win_lo, &c->win_n, &c->tab_off, &c->table, &c->cls_list, &c->counters,
-                      &c->scratch, &c->state_i32, &c->state_f64, &c->spec, &c->win_lo2, &c->win_n2, &c->tab_off2, &c->table2,
+                      &c->scratch, &c->state_i32, &c->state_f64, &c->spec, &c->rhash, &c->rep, &c->win_lo2, &c->win_n2, &c->tab_off2, &c->table2,
                       &c->items, &c->in_seqs, &c->in_seq_off, &c->in_nfl, &c->in_ntr, &c->in_nfr, &c->in_est,
                       &c->in_read_off, &c->in_motifs, &c->in_motif_off, &c->out_cn, &c->out_score, &c->out_n,
                       &c->out_start};

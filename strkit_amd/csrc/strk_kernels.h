@@ -70,6 +70,8 @@ struct KArgs {
     long long scratch_cap;      // in int32 units
     unsigned long long* scratch_used;
     int4* spec;           // [n_reads] speculative search result for start == est_cn (or NULL)
+    unsigned long long* rhash;  // [n_reads] content hash of each read window (dedupe) or NULL
+    int32_t* rep;         // [n_reads] earliest identical read of the same locus (itself if none)
     int32_t list_stride;
     int32_t end_flags;
     int32_t window;       // half width (plan kernel)
@@ -82,7 +84,8 @@ enum Counter {
     kCntMiss = kNumClasses + 1,           // loci whose search left the table window
     kCntError = kNumClasses + 2,          // sticky error bits
     kCntNextChunk = kNumClasses + 3,      // work queue head of k_dp_all
-    kCntTotal = kNumClasses + 4
+    kCntDup = kNumClasses + 4,            // reads that share the score table of an identical earlier read
+    kCntTotal = kNumClasses + 5
 };
 constexpr int kErrBadInput = 1;   // empty motif / negative length
 constexpr int kErrScratch = 2;    // generic scratch exhausted
@@ -101,6 +104,55 @@ __device__ inline int classify(int nfl, int ntr, int nfr, int m, int lo, int n, 
         if (ndb + 1 <= cap && rows <= cap + kRowSlack) return c;
     }
     return kGenericClass;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dedupe (the device-side counterpart of the reference's lru_cache, strkit/call/repeats.py:47):
+// reads of one locus with byte-identical fl|tr|fr, equal split lengths and equal start estimate
+// share ONE score table.  k_hash gives every read a 64-bit content hash; k_plan compares a read
+// with the earlier reads of its locus (hash first, then every byte) and lists only first occurrences.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long hash_mix(unsigned long long h, unsigned long long v) {
+    h ^= v;
+    h *= 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+
+__global__ void __launch_bounds__(256) k_hash(KArgs a) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    const uint8_t* p = a.seqs + a.seq_off[r];
+    const int len = (int)(a.seq_off[r + 1] - a.seq_off[r]);
+    unsigned long long h = 0xCBF29CE484222325ull;
+    int i = 0;
+    for (; i + 8 <= len; i += 8) {
+        unsigned long long v;
+        __builtin_memcpy(&v, p + i, 8);
+        h = hash_mix(h, v);
+    }
+    unsigned long long tail = 0;
+    for (int k = 0; i + k < len; ++k) tail |= (unsigned long long)p[i + k] << (8 * k);
+    h = hash_mix(h, tail);
+    h = hash_mix(h, ((unsigned long long)(unsigned)a.nfl[r] << 32) | (unsigned)a.ntr[r]);
+    h = hash_mix(h, ((unsigned long long)(unsigned)a.nfr[r] << 32) | (unsigned)a.est_cn[r]);
+    a.rhash[r] = h;
+}
+
+__device__ inline bool same_read(const KArgs& a, int r, int q) {
+    if (a.nfl[r] != a.nfl[q] || a.ntr[r] != a.ntr[q] || a.nfr[r] != a.nfr[q] || a.est_cn[r] != a.est_cn[q]) return false;
+    const uint8_t* x = a.seqs + a.seq_off[r];
+    const uint8_t* y = a.seqs + a.seq_off[q];
+    const int len = a.nfl[r] + a.ntr[r] + a.nfr[r];
+    int i = 0;
+    for (; i + 8 <= len; i += 8) {
+        unsigned long long u, v;
+        __builtin_memcpy(&u, x + i, 8);
+        __builtin_memcpy(&v, y + i, 8);
+        if (u != v) return false;
+    }
+    for (; i < len; ++i)
+        if (x[i] != y[i]) return false;
+    return true;
 }
 
 // mode 0: windows from est_cn +/- window, table slot r*table_stride;
@@ -140,9 +192,20 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
             if (w_hi - w_lo + 1 > a.table_stride) w_hi = w_lo + a.table_stride - 1;
             lo = (int)w_lo;
             n = (int)(w_hi - w_lo + 1);
+            int rep = r;
+            if (a.rhash) {
+                const unsigned long long h = a.rhash[r];
+                for (int q = a.read_off[l]; q < r; ++q)
+                    if (a.rhash[q] == h && same_read(a, r, q)) { rep = q; break; }  // first occurrence
+            }
+            a.rep[r] = rep;
             a.win_lo[r] = lo;
             a.win_n[r] = n;
-            a.tab_off[r] = (int64_t)r * a.table_stride;
+            a.tab_off[r] = (int64_t)rep * a.table_stride;
+            if (rep != r) {
+                n = 0;  // no DP item: the table (and the speculative search) of `rep` serve this read too
+                atomicAdd(&a.counters[kCntDup], 1);
+            }
         } else {
             lo = a.win_lo[r];
             n = a.win_n[r];
@@ -190,15 +253,22 @@ constexpr int kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;  // gfx9 DPP controls,
 constexpr int kCLMax = 28;   // columns per lane of the largest class
 constexpr int kNQMax = kCLMax / 4;
 
-// lane l gets v of lane l-1 (wave_shr:1); the first lane of every group gets `keep` instead
-__device__ __forceinline__ int from_left(int keep, int v, bool first) {
+constexpr int kDppRowShr1 = 0x111, kDppRowShl1 = 0x101;
+// from_left<G>(keep, v): lane l gets v of lane l-1; the first lane of every group gets `keep`.
+//   G = 16: a DPP row is one group (row_shr:1 leaves `keep` in its first lane);
+//   G = 64: wave_shr:1;  G = 32: wave_shr:1, then a select patches the seam lane (32 / 31).
+// `keep` must be wave-uniform (it is the boundary value of the group's edge lane at this step).
+template <int G>
+__device__ __forceinline__ int from_left(int keep, int v, bool edge_lane) {
+    if (G == 16) return __builtin_amdgcn_update_dpp(keep, v, kDppRowShr1, 0xf, 0xf, false);
     const int x = __builtin_amdgcn_update_dpp(keep, v, kDppWaveShr1, 0xf, 0xf, false);
-    return first ? keep : x;
+    return (G == 32 && edge_lane) ? keep : x;
 }
-// lane l gets v of lane l+1 (wave_shl:1); the last lane of every group gets `keep` instead
-__device__ __forceinline__ int from_right(int keep, int v, bool last) {
+template <int G>
+__device__ __forceinline__ int from_right(int keep, int v, bool edge_lane) {
+    if (G == 16) return __builtin_amdgcn_update_dpp(keep, v, kDppRowShl1, 0xf, 0xf, false);
     const int x = __builtin_amdgcn_update_dpp(keep, v, kDppWaveShl1, 0xf, 0xf, false);
-    return last ? keep : x;
+    return (G == 32 && edge_lane) ? keep : x;
 }
 
 // LDS operations of one group never leave its wave: order them with a wave-level fence.
@@ -268,7 +338,7 @@ __device__ __forceinline__ int dp_row(const int (&src)[4 * NQ], int (&dst)[4 * N
 // Backward pass over the fr rows (k' = 1..rowsT consume fr[rowsT-k']).  Slot s holds node j = s
 // (db chars s.. remain) for s < ndb; slots >= ndb are inert pads that carry the boundary value.
 // Leaves Gb(rowsT, .) in LDS (b0) and returns max_{k'<rowsT} (Gb(k', 0) - g*k') for lane 0.
-template <int NQ>
+template <int NQ, int G>
 __device__ __forceinline__ int bwd_pass(const PassCtx& x, int rowsT, const uint8_t* ct) {
     constexpr int g = kGap, CL = 4 * NQ;
     int Ha[CL], Hb[CL];
@@ -282,13 +352,12 @@ __device__ __forceinline__ int bwd_pass(const PassCtx& x, int rowsT, const uint8
         if (s < x.ndb && x.dbEnd) v = g * (x.ndb - s) - (s == 0 ? g : 0);
         Ha[c] = v;
     }
-    const int G = x.G;
     const int Tb = (wave_max_over_groups(rowsT > 0 ? rowsT + G - 1 : 0) + 1) & ~1;
     const int bstep = x.cEnd ? g : 0;
     const int gkEvent = g * rowsT;
     int zsave = 0;
     int hout = Ha[0];
-    int edgePrev = from_right(0, hout, x.last);
+    int edgePrev = from_right<G>(0, hout, x.last);
     int gk = g * (x.lig - (G - 1));   // g * k' of the row this lane finished before step 0
     int zmax = Ha[0];
     const uint8_t* pa = ct + x.lig;   // row symbol of step t is pa[t]
@@ -299,7 +368,7 @@ __device__ __forceinline__ int bwd_pass(const PassCtx& x, int rowsT, const uint8
         const uint2 word = wordNext;                                                         \
         wordNext = x.tbl[symNext];                                                           \
         symNext = pa[(T) + 2];                                                               \
-        const int edge = from_right(bstep * ((T) + 1), hout, x.last);                        \
+        const int edge = from_right<G>(bstep * ((T) + 1), hout, x.last);                        \
         hout = dp_row<NQ, false>(SRC, DST, sel, word, edge, edgePrev);                       \
         edgePrev = edge;                                                                     \
         gk += g;                                                                             \
@@ -324,7 +393,7 @@ __device__ __forceinline__ int bwd_pass(const PassCtx& x, int rowsT, const uint8
 // s = 1..ndb holds node j = s (consumes db[s-1]); slots > ndb replicate the last column.  At the
 // fork rows R_k = nfl + (lo+k)*m it folds max_s(Gf + Gb) into comb[k] and records the running
 // last-column maximum in lmaxA[k].
-template <int NQ>
+template <int NQ, int G>
 __device__ __forceinline__ void fwd_pass(const PassCtx& x, int rowsP, const uint8_t* cp, int nEff, int fork0, int m,
                                          int* comb, int* lmaxA) {
     constexpr int g = kGap, CL = 4 * NQ;
@@ -334,12 +403,11 @@ __device__ __forceinline__ void fwd_pass(const PassCtx& x, int rowsP, const uint
     for (int q = 0; q < NQ; ++q) sel[q] = x.act ? __builtin_amdgcn_alignbyte(x.selw[q + 1], x.selw[q], 3) : 0x0c0c0c0cu;
 #pragma unroll
     for (int c = 0; c < CL; ++c) Ha[c] = x.dbBeg ? g * min(x.lig * CL + c, x.ndb) : 0;
-    const int G = x.G;
     const int Tf = (wave_max_over_groups(nEff > 0 ? rowsP + G - 1 : 0) + 1) & ~1;
     const int bstep = x.cBeg ? g : 0;
     const int gm = g * m;
     int hout = Ha[CL - 1];
-    int edgePrev = from_left(0, hout, x.first);
+    int edgePrev = from_left<G>(0, hout, x.first);
     int gr = -g * x.lig;           // g * row this lane finished before step 0
     int lastmax = kNegInf;
     int forkG = nEff > 0 ? g * fork0 : 0x7fffffff;
@@ -352,7 +420,7 @@ __device__ __forceinline__ void fwd_pass(const PassCtx& x, int rowsP, const uint
         const uint2 word = wordNext;                                                         \
         wordNext = x.tbl[symNext];                                                           \
         symNext = pa[(T) + 2];                                                               \
-        const int edge = from_left(bstep * ((T) + 1), hout, x.first);                        \
+        const int edge = from_left<G>(bstep * ((T) + 1), hout, x.first);                        \
         hout = dp_row<NQ, true>(SRC, DST, sel, word, edge, edgePrev);                        \
         edgePrev = edge;                                                                     \
         gr += g;                                                                             \
@@ -539,25 +607,32 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     x.selw = reinterpret_cast<const unsigned*>(dbs) + lig * nq;
     x.b0 = reinterpret_cast<uint2*>(Lg + lay.off_b0) + lig;
 
-    int zsave;
-    switch (nq) {
-    case 2: zsave = bwd_pass<2>(x, rowsT, ct); break;
-    case 3: zsave = bwd_pass<3>(x, rowsT, ct); break;
-    case 4: zsave = bwd_pass<4>(x, rowsT, ct); break;
-    case 5: zsave = bwd_pass<5>(x, rowsT, ct); break;
-    case 6: zsave = bwd_pass<6>(x, rowsT, ct); break;
-    default: zsave = bwd_pass<7>(x, rowsT, ct); break;
-    }
-    if (first) misc[1] = zsave;
+    // the two hot loops are specialised on (CL/4, G): 14 instances each, everything else is one body
+    int zsave = 0;
     const int fork0 = nfl + lo * m;
-    switch (nq) {
-    case 2: fwd_pass<2>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
-    case 3: fwd_pass<3>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
-    case 4: fwd_pass<4>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
-    case 5: fwd_pass<5>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
-    case 6: fwd_pass<6>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
-    default: fwd_pass<7>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); break;
+#define STRK_PASSES(NQ_, G_)                                             \
+    {                                                                    \
+        zsave = bwd_pass<NQ_, G_>(x, rowsT, ct);                          \
+        if (first) misc[1] = zsave;                                      \
+        fwd_pass<NQ_, G_>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA);     \
     }
+    switch (cls) {
+    case 0: STRK_PASSES(2, 16) break;
+    case 1: STRK_PASSES(3, 16) break;
+    case 2: STRK_PASSES(4, 16) break;
+    case 3: STRK_PASSES(5, 16) break;
+    case 4: STRK_PASSES(6, 16) break;
+    case 5: STRK_PASSES(7, 16) break;
+    case 6: STRK_PASSES(4, 32) break;
+    case 7: STRK_PASSES(5, 32) break;
+    case 8: STRK_PASSES(6, 32) break;
+    case 9: STRK_PASSES(7, 32) break;
+    case 10: STRK_PASSES(4, 64) break;
+    case 11: STRK_PASSES(5, 64) break;
+    case 12: STRK_PASSES(6, 64) break;
+    default: STRK_PASSES(7, 64) break;
+    }
+#undef STRK_PASSES
     wave_lds_sync();
     // ---- assemble S[lo + k] (fields re-read from the kernarg segment: nothing was kept live) -----
     KArgsKernarg ap2 = ap;
@@ -584,7 +659,8 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     }
     wave_lds_sync();
 }
-static_assert(kCLMax == 28, "dp_wave dispatches CL/4 = 2..7");
+static_assert(kCLMax == 28 && kNumClasses == 14 && class_CL(0) == 8 && class_CL(6) == 16 && class_CL(10) == 16,
+              "dp_wave dispatches the 14 (CL/4, G) classes by index");
 
 // All fast classes in ONE launch: every wave pulls chunks (one item per group) from a device-side
 // queue, most expensive classes first.
@@ -712,7 +788,7 @@ __global__ void __launch_bounds__(64) k_replay(KArgs a, ReplayArgs p) {
         const int rl = base + lane;
         const int my_est = lane < cnt ? a.est_cn[rl] : 0;
         int4 my_spec = make_int4(0, 0, 0, kSpecMiss);
-        if (a.spec && lane < cnt) my_spec = a.spec[rl];
+        if (a.spec && lane < cnt) my_spec = a.spec[a.rep[rl]];
         int o_cn = 0, o_score = 0, o_n = 0, o_start = 0;
         int done = 0;
         for (int i = 0; i < cnt; ++i) {

@@ -80,3 +80,26 @@ def test_empty_and_ragged_batches(gpu_ctx):
     exp = oracle_count(b)
     for k in KEYS:
         assert np.array_equal(got[k], exp[k])
+
+
+def test_identical_reads_share_one_table(gpu_ctx):
+    """Dedupe (the device-side lru_cache): byte-identical reads of a locus are scored once; answers do
+    not change, including when the start-count feedback gives the copies different starts."""
+    rng = np.random.default_rng(24)
+    loci = []
+    for _ in range(30):
+        motif, reads = random_locus(rng, 3, motif_len=(2, 6), cn=(4, 30), flank=(40, 70), alpha=ALPHA_WC)
+        reads = [reads[i % 3] for i in rng.integers(0, 3, size=12)]  # many copies, shuffled
+        loci.append((motif, reads))
+    b = LocusBatch.from_reads(loci)
+    b.est_cn[::7] += 2        # same bytes but another estimate: must NOT be merged
+    b.est_cn[3::11] = np.maximum(0, b.est_cn[3::11] - 3)
+    exp = oracle_count(b)
+    got, st = _run(b, gpu_ctx)
+    _compare(b, got, exp)
+    assert st["n_dedup_reads"] > b.n_reads // 3
+    got2, st2 = _run(b, gpu_ctx, dedupe=False)
+    _compare(b, got2, exp)
+    assert st2["n_dedup_reads"] == 0 and st2["dp_cells"] > st["dp_cells"]
+    got3, _ = _run(b, gpu_ctx, window=1)  # copies through the miss path too
+    _compare(b, got3, exp)
