@@ -45,7 +45,7 @@ def _cpu_worker(args):
         r0, r1 = int(b.read_off[l]), int(b.read_off[l + 1])
         s0 = int(b.seq_off[r0])
         o = oracle.count_locus(b.seqs[s0:int(b.seq_off[r1])], b.seq_off[r0:r1 + 1] - s0, b.nfl[r0:r1], b.ntr[r0:r1],
-                               b.nfr[r0:r1], b.est_cn[r0:r1], b.motif(l))
+                               b.nfr[r0:r1], b.est_cn[r0:r1], b.motif(l), memo=True)  # lru_cache, repeats.py:47
         cells += o["cells"]
     return b.n_reads, time.perf_counter() - t0, cells
 
@@ -67,8 +67,9 @@ def cpu_baseline(cfg: int, sample_loci: int) -> dict:
     reads = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
     return {"value": reads / busy, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {per * cores} loci ({reads} reads) of the same workload, scalar C oracle, "
-                      f"{cores} processes, {busy:.1f} s busy ({wall:.1f} s wall incl. input generation)",
+            "sample": f"first {per * cores} loci ({reads} reads) of the same workload, scalar C oracle with the reference's "
+                      f"per-locus memoisation, {cores} processes, {busy:.1f} s busy each "
+                      f"({busy * cores:.0f} core-seconds; {wall:.1f} s wall incl. input generation)",
             "reads_per_s_per_core": reads / busy / cores, "gcups": sum(r[2] for r in res) / busy / 1e9}
 
 
@@ -82,7 +83,7 @@ def main() -> None:
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--no-dedupe", action="store_true", help="score identical reads of a locus separately")
     ap.add_argument("--pipeline", type=int, default=3, help="batched calls in flight (contexts/streams)")
-    ap.add_argument("--cpu-sample-loci", type=int, default=256)
+    ap.add_argument("--cpu-sample-loci", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -185,6 +186,18 @@ def main() -> None:
         iso_dp += st.dp_kernel_ms / 5; iso_all += st.kernel_ms / 5
     fence()
 
+    def pmc_traffic():
+        """HBM bytes per k_dp_all launch from the committed rocprofv3 PMC passes of this same command
+        (profiles/README.md): FETCH_SIZE and WRITE_SIZE are in KiB and were collected in separate passes;
+        FETCH_SIZE is doubled, the guide's gfx950 correction (calibrated here on k_hash, which reads every
+        input byte exactly once: raw FETCH_SIZE = 0.49 x bytes)."""
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_b_pmc_summary.json")) as f:
+                k = json.load(f)["k_dp_all"]
+            return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        except Exception:  # noqa: BLE001
+            return None
+
     if rank == 0:
         # sanity: the timed path's answers on the first loci agree with the oracle (checker only)
         import oracle
@@ -212,7 +225,8 @@ def main() -> None:
                        "calls_in_flight": D},
             "loci_per_s": n_loci_all * a.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": alg_bytes / dp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg_bytes / dp_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": alg_bytes / dp_s / 1e9 / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic() if (a.config == 2 and a.loci is None and not a.no_dedupe) else None,
                          "kernel": "strk::k_dp_all",
                          "kernel_ms": dp_ms / a.steps, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer max-plus DP: the binding unit is VALU issue (see valu); kernel_ms is the HIP-event "

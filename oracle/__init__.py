@@ -51,7 +51,7 @@ def lib():
         L.strk_o_repeat_count.restype = C.c_int
         L.strk_o_repeat_count.argtypes = ([C.c_int32] + [_u8p, C.c_int32] * 4 + [C.c_int32] * 5 + [_i32p, _i32p, _i32p, _i64p])
         L.strk_o_count_locus.restype = C.c_int
-        L.strk_o_count_locus.argtypes = ([C.c_int32, _u8p, _i64p, _i32p, _i32p, _i32p, _i32p, _u8p] + [C.c_int32] * 7
+        L.strk_o_count_locus.argtypes = ([C.c_int32, _u8p, _i64p, _i32p, _i32p, _i32p, _i32p, _u8p] + [C.c_int32] * 8
                                          + [_i32p, _i32p, _i32p, _i32p, _i64p])
         L.strk_o_score_ref_boundaries.restype = None
         L.strk_o_score_ref_boundaries.argtypes = [_u8p, C.c_int32] * 4 + [C.c_int32, C.c_int32, _i32p]
@@ -108,7 +108,7 @@ def repeat_count(start_count: int, tr, fl, fr, motif, max_iters: int = 50, lsr: 
 
 def count_locus(seqs: np.ndarray, off: np.ndarray, nfl: np.ndarray, ntr: np.ndarray, nfr: np.ndarray,
                 est_cn: np.ndarray, motif, max_iters: int = 50, lsr: int = 3, step: int = 1,
-                tie_rule: int = TIE_FIRST, flags: int = SG_ALL, feedback: bool = True):
+                tie_rule: int = TIE_FIRST, flags: int = SG_ALL, feedback: bool = True, memo: bool = False):
     """One locus, reads in order with the caller's start-count feedback (call_locus.py:1125-1161).
 
     Returns dict of int32 arrays cn, score, n_iters, start and the DP cell count."""
@@ -124,7 +124,7 @@ def count_locus(seqs: np.ndarray, off: np.ndarray, nfl: np.ndarray, ntr: np.ndar
     if seqs.size == 0:
         seqs = np.zeros(1, np.uint8)
     rc = lib().strk_o_count_locus(n, p(seqs, _u8p), p(off, _i64p), p(nfl, _i32p), p(ntr, _i32p), p(nfr, _i32p),
-                                  p(est_cn, _i32p), bm, nm, max_iters, lsr, step, tie_rule, flags, int(feedback),
+                                  p(est_cn, _i32p), bm, nm, max_iters, lsr, step, tie_rule, flags, int(feedback), int(memo),
                                   p(out["cn"], _i32p), p(out["score"], _i32p), p(out["n_iters"], _i32p),
                                   p(out["start"], _i32p), C.byref(cells))
     if rc:

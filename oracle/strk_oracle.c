@@ -336,7 +336,7 @@ static int64_t py_round(double x) { return (int64_t)nearbyint(x); }
 int strk_o_count_locus(int32_t n_reads, const uint8_t* seqs, const int64_t* off, const int32_t* nfl,
                        const int32_t* ntr, const int32_t* nfr, const int32_t* est_cn,
                        const uint8_t* motif, int32_t m, int32_t max_iters, int32_t lsr, int32_t step,
-                       int32_t tie_rule, int32_t flags, int32_t feedback, int32_t* out_cn,
+                       int32_t tie_rule, int32_t flags, int32_t feedback, int32_t memo, int32_t* out_cn,
                        int32_t* out_score, int32_t* out_n, int32_t* out_start, int64_t* out_cells) {
     double frac = 0.0;
     int64_t cells = 0;
@@ -350,10 +350,23 @@ int strk_o_count_locus(int32_t n_reads, const uint8_t* seqs, const int64_t* off,
         }
         int32_t cn = 0, sc = 0, n = 0;
         int64_t cl = 0;
-        int rc = strk_o_repeat_count((int32_t)read_sc, base + nfl[r], ntr[r], base, nfl[r],
-                                     base + nfl[r] + ntr[r], nfr[r], motif, m, max_iters, lsr, step,
-                                     tie_rule, flags, &cn, &sc, &n, &cl);
-        if (rc) return rc;
+        int hit = 0;
+        if (memo) {
+            /* the reference memoises get_repeat_count on its full argument tuple with
+             * functools.lru_cache (repeats.py:47): an identical earlier call of this locus is a hit */
+            for (int32_t q = 0; q < r && !hit; q++) {
+                if (out_start[q] != (int32_t)read_sc || nfl[q] != nfl[r] || ntr[q] != ntr[r] || nfr[q] != nfr[r]) continue;
+                if (memcmp(seqs + off[q], base, (size_t)(nfl[r] + ntr[r] + nfr[r])) != 0) continue;
+                cn = out_cn[q]; sc = out_score[q]; n = out_n[q];
+                hit = 1;
+            }
+        }
+        if (!hit) {
+            int rc = strk_o_repeat_count((int32_t)read_sc, base + nfl[r], ntr[r], base, nfl[r],
+                                         base + nfl[r] + ntr[r], nfr[r], motif, m, max_iters, lsr, step,
+                                         tie_rule, flags, &cn, &sc, &n, &cl);
+            if (rc) return rc;
+        }
         cells += cl;
         out_cn[r] = cn;
         out_score[r] = sc;
