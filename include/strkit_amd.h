@@ -14,6 +14,9 @@
  *   strk_submit_loci_device / strk_finish   the same loop, split so that successive blocks of loci
  *                            overlap on the device (the reference overlaps them across its worker
  *                            processes, strkit/call/call_sample.py:414)
+ *   strk_ref_repeat_count    get_ref_repeat_count() incl. score_ref_boundaries(), once per locus
+ *                            — strkit/call/repeats.py:23-43,73-192 (parasail sg_qe_scan_profile_sat);
+ *                            strk_score_ref_table is its scoring primitive
  *   strk_score_table         one parasail semi-global alignment score per candidate copy number
  *                            (the innermost operation; shape of strkit/call/repeats.py:33,40,124)
  *
@@ -140,6 +143,24 @@ int strk_finish(strk_ctx* ctx, strk_stats* stats);
 int strk_score_table(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, const int32_t* n,
                      const int64_t* table_off, int32_t end_flags, int32_t force_generic,
                      int32_t* scores, strk_stats* stats);
+
+/* Reference-side primitive (score_ref_boundaries, repeats.py:23-43): for k < n[r],
+ * scores[table_off[r] + k] / end_query[...] = parasail sg_qe score and query end of the candidate
+ * fl + motif*(lo[r]+k) (NO right flank) against the window fl+tr+fr whose end is free.  For the
+ * reversed alignment pass the reversed window with the flanks swapped and the reversed motif.  HOST buffers. */
+int strk_score_ref_table(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, const int32_t* n,
+                         const int64_t* table_off, int32_t force_generic, int32_t* scores,
+                         int32_t* end_query, strk_stats* stats);
+
+/* Drop-in for get_ref_repeat_count (repeats.py:73-192), once per locus: boundary-extension search
+ * + final count.  out9 = {cn, score, l_offset, r_offset, n_offset_scores, n_iters_final,
+ * new fl_len, new tr_len, new fr_len} (the bases never change, only where the flank/tract
+ * boundaries fall inside fl|tr|fr). */
+int strk_ref_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int32_t tr_len,
+                          const uint8_t* fl, int32_t fl_len, const uint8_t* fr, int32_t fr_len,
+                          const uint8_t* motif, int32_t motif_len, int32_t ref_size,
+                          int32_t vcf_anchor_size, int32_t max_iters, int32_t local_search_range,
+                          int32_t step_size, int32_t respect_coords, int32_t* out9);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,8 @@ class StrkStats(C.Structure):
 
 # Every symbol include/strkit_amd.h declares (tests check the .so exports exactly these).
 EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_repeat_count", "strk_count_loci",
-           "strk_count_loci_device", "strk_submit_loci_device", "strk_finish", "strk_score_table")
+           "strk_count_loci_device", "strk_submit_loci_device", "strk_finish", "strk_score_table",
+           "strk_score_ref_table", "strk_ref_repeat_count")
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -97,6 +98,12 @@ def load(build: bool = True):
         L.strk_score_table.restype = C.c_int
         L.strk_score_table.argtypes = [C.c_void_p, C.POINTER(StrkBatch), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int32, C.c_int32, C.c_void_p, C.POINTER(StrkStats)]
+        L.strk_score_ref_table.restype = C.c_int
+        L.strk_score_ref_table.argtypes = [C.c_void_p, C.POINTER(StrkBatch), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(StrkStats)]
+        L.strk_ref_repeat_count.restype = C.c_int
+        L.strk_ref_repeat_count.argtypes = ([C.c_void_p, C.c_int32] + [C.c_char_p, C.c_int32] * 4 + [C.c_int32] * 6
+                                            + [_i32p])
         _lib = L
         return L
 

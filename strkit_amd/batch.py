@@ -14,7 +14,7 @@ from . import _lib
 from .repeat_count_params import RepeatCountParams, default_read_rc_params
 from .synth import LocusBatch
 
-__all__ = ["count_loci", "score_table", "make_params", "batch_struct"]
+__all__ = ["count_loci", "score_table", "score_ref_table", "make_params", "batch_struct"]
 
 
 def make_params(rc_params: RepeatCountParams | None = None, feedback: bool = True, window: int = 0,
@@ -81,3 +81,22 @@ def score_table(b: LocusBatch, lo, n, end_flags: int = _lib.STRK_SG_ALL, force_g
     del keep
     res = [flat[off[r]:off[r + 1]] for r in range(b.n_reads)]
     return (res, st.as_dict()) if with_stats else res
+
+
+def score_ref_table(b: LocusBatch, lo, n, force_generic: bool = False, ctx: _lib.Context | None = None):
+    """Reference-side scoring (score_ref_boundaries, strkit/call/repeats.py:23-43): per read r two int32
+    arrays (score, end_query) of the candidate fl + motif*i, i = lo[r] .. lo[r]+n[r]-1, against the
+    window fl+tr+fr with a free end.  For the reversed alignment pass the reversed window."""
+    ctx = ctx or _lib.default_context()
+    lo = np.ascontiguousarray(lo, np.int32)
+    n = np.ascontiguousarray(n, np.int32)
+    off = np.zeros(b.n_reads + 1, np.int64)
+    np.cumsum(n, out=off[1:])
+    sc = np.zeros(max(int(off[-1]), 1), np.int32)
+    eq = np.zeros(max(int(off[-1]), 1), np.int32)
+    s, keep = batch_struct(b)
+    st = _lib.StrkStats()
+    _lib.check(_lib.load().strk_score_ref_table(ctx.handle, C.byref(s), _ptr(lo), _ptr(n), _ptr(off), int(force_generic),
+                                                _ptr(sc), _ptr(eq), C.byref(st)))
+    del keep
+    return [(sc[off[r]:off[r + 1]], eq[off[r]:off[r + 1]]) for r in range(b.n_reads)]

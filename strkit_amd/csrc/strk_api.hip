@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -16,6 +17,11 @@
 
 #include "../../include/strkit_amd.h"
 #include "strk_kernels.h"
+
+extern "C" int strk_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int32_t tr_len, const uint8_t* fl,
+                                 int32_t fl_len, const uint8_t* fr, int32_t fr_len, const uint8_t* motif, int32_t motif_len,
+                                 int32_t max_iters, int32_t local_search_range, int32_t step_size, int32_t* out_cn,
+                                 int32_t* out_score, int32_t* out_n_explored);
 
 namespace {
 
@@ -170,7 +176,8 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     if (!force_generic) {
         // persistent-style grid: every wave pulls chunks from the device-side queue until it is empty
         const int blocks = std::max(1, std::min(256 * 4, (a.list_stride + 3) / 4));
-        hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);
+        if (a.ref_mode) hipLaunchKernelGGL(k_dp_ref, dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(k_dp_generic, dim3(256), dim3(256), 0, st, a);
     if (time_dp) (void)hipEventRecord(c->ev[2], st);
@@ -456,6 +463,212 @@ int upload_batch(strk_ctx* c, const strk_batch* b, strk_batch* d, hipStream_t st
     return 0;
 }
 
+
+// strk_score_table / strk_score_ref_table: explicit candidate windows per read, HOST buffers.
+// ref_mode = 1 scores the reference-side candidate fl + motif*i (no right flank) and also returns
+// the db position where the alignment ends (repeats.py:23-43).
+int score_table_impl(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, const int32_t* n,
+                     const int64_t* table_off, int32_t end_flags, int32_t force_generic, int32_t ref_mode,
+                     int32_t* scores, int32_t* end_query, strk_stats* stats) {
+    if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
+    if (ctx->pending) return fail(STRK_E_INVALID, "context holds a submitted call: strk_finish() it first");
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (end_flags < 0 || end_flags > 15) return fail(STRK_E_INVALID, "bad end_flags");
+    strk_batch d;
+    int rc;
+    if ((rc = upload_batch(ctx, batch, &d, nullptr))) return rc;
+    if (batch->n_reads == 0 || batch->n_loci == 0) return 0;
+    if (!lo || !n || !table_off || !scores) return fail(STRK_E_INVALID, "lo / n / table_off / scores is NULL");
+    const size_t nr = (size_t)batch->n_reads;
+    const int mul = ref_mode ? 2 : 1;
+    size_t n_chunks = 0;
+    for (size_t r = 0; r < nr; ++r) {
+        if (lo[r] < 0 || n[r] < 0) return fail(STRK_E_INVALID, "read %zu: negative window", r);
+        if (table_off[r + 1] - table_off[r] < n[r] || table_off[r] < 0) return fail(STRK_E_INVALID, "read %zu: table_off too small", r);
+        n_chunks += ((size_t)n[r] + kTableMax - 1) / kTableMax;
+    }
+    const size_t tab = (size_t)table_off[nr];
+    if ((rc = ensure_workspace(ctx, batch->n_reads, batch->n_loci, tab * mul, std::max<size_t>(n_chunks, 1)))) return rc;
+    KArgs a = make_args(ctx, &d, end_flags, 0, 0, (int)std::max<size_t>(n_chunks, 1), nullptr);
+    a.ref_mode = ref_mode;
+    hipStream_t st = nullptr;
+    std::vector<int64_t> off_dev(table_off, table_off + nr);
+    for (auto& o : off_dev) o *= mul;
+    HIP_TRY(hipMemcpyAsync(a.win_lo, lo, nr * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(a.win_n, n, nr * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(a.tab_off, off_dev.data(), nr * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, kCountersBytes, st));
+    HIP_TRY(hipEventRecord(ctx->ev[0], st));
+    enqueue_scoring(ctx, a, 1, nullptr, batch->n_reads, force_generic, st, true);
+    HIP_TRY(hipEventRecord(ctx->ev[3], st));
+    HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if ((rc = check_error_bits(ctx->h_counters[kCntError]))) return rc;
+    if (tab) {
+        if (!ref_mode) {
+            HIP_TRY(hipMemcpy(scores, a.table, tab * 4, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<int32_t> pairs(tab * 2);
+            HIP_TRY(hipMemcpy(pairs.data(), a.table, tab * 8, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < tab; ++k) {
+                scores[k] = pairs[2 * k];
+                end_query[k] = pairs[2 * k + 1];
+            }
+        }
+    }
+    if (stats) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) stats->kernel_ms = ms;
+        if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) stats->dp_kernel_ms = ms;
+        stats->n_dp_launches = 2;
+        stats->n_fallback = ctx->h_counters[kCntClass0 + kGenericClass];
+        stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->h_counters) + kCellsOff);
+    }
+    return 0;
+}
+
+// Lazily scored (fwd score, fwd end_query, rev score, rev end_query) per candidate size for one locus:
+// two device "reads" — the window itself and its reversal with the flanks swapped
+// (repeats.py:32-41: ext_l_seq = (tr_candidate + flank_right_seq)[::-1] against db_seq[::-1]).
+struct RefScorer {
+    strk_ctx* ctx;
+    std::vector<uint8_t> seqs, motifs;
+    int64_t seq_off[3];
+    int32_t nfl[2], ntr[2], nfr[2], read_off[3], motif_off[3];
+    int32_t step;
+    std::vector<int64_t> sizes;                 // cached sizes (unordered)
+    std::vector<std::array<int32_t, 4>> vals;   // fs, fe, rs, re
+    int find(int64_t i) const {
+        for (size_t k = 0; k < sizes.size(); ++k)
+            if (sizes[k] == i) return (int)k;
+        return -1;
+    }
+    int ensure(int64_t w_lo, int64_t w_hi) {  // make every size in [w_lo, w_hi] available
+        bool all = true;
+        for (int64_t i = w_lo; i <= w_hi && all; ++i) all = find(i) >= 0;
+        if (all) return 0;
+        const int64_t pad = step == 1 ? 8 : 0;   // dense look-ahead only pays for unit steps
+        int64_t lo = std::max<int64_t>(0, w_lo - pad), hi = w_hi + pad;
+        if (hi - lo + 1 > 4096) return fail(STRK_E_INVALID, "reference-side window too wide");
+        const int32_t n = (int32_t)(hi - lo + 1);
+        const int32_t los[2] = {(int32_t)lo, (int32_t)lo}, ns[2] = {n, n};
+        const int64_t toff[3] = {0, n, 2 * (int64_t)n};
+        std::vector<int32_t> sc(2 * (size_t)n), eq(2 * (size_t)n);
+        strk_batch b;
+        b.n_reads = 2; b.n_loci = 2;
+        b.seqs = seqs.data(); b.seq_off = seq_off; b.nfl = nfl; b.ntr = ntr; b.nfr = nfr; b.est_cn = nullptr;
+        b.read_off = read_off; b.motifs = motifs.data(); b.motif_off = motif_off;
+        const int rc = score_table_impl(ctx, &b, los, ns, toff, STRK_DB_END_FREE, 0, 1, sc.data(), eq.data(), nullptr);
+        if (rc) return rc;
+        for (int32_t k = 0; k < n; ++k) {
+            if (find(lo + k) >= 0) continue;
+            sizes.push_back(lo + k);
+            vals.push_back({sc[k], eq[k], sc[n + k], eq[n + k]});
+        }
+        return 0;
+    }
+};
+
+// get_ref_repeat_count (strkit/call/repeats.py:73-192): boundary-extension search on the device-scored
+// (score, end_query) pairs, then the final read-style count on the adjusted flank/tract split.
+int ref_repeat_count_impl(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int32_t ntr, const uint8_t* fl,
+                          int32_t nfl, const uint8_t* fr, int32_t nfr, const uint8_t* motif, int32_t m, int32_t ref_size,
+                          int32_t vcf_anchor_size, int32_t max_iters, int32_t lsr, int32_t step, int32_t respect_coords,
+                          int32_t* out9) {
+    const int32_t ndb = nfl + ntr + nfr;
+    std::vector<uint8_t> db((size_t)ndb);
+    if (nfl) memcpy(db.data(), fl, (size_t)nfl);
+    if (ntr) memcpy(db.data() + nfl, tr, (size_t)ntr);
+    if (nfr) memcpy(db.data() + nfl + ntr, fr, (size_t)nfr);
+    int32_t l_offset = 0, r_offset = 0, n_off = 0;
+    if (!respect_coords) {
+        RefScorer sc;
+        sc.ctx = ctx;
+        sc.step = step;
+        sc.seqs.resize(2 * (size_t)ndb);
+        memcpy(sc.seqs.data(), db.data(), (size_t)ndb);
+        for (int32_t i = 0; i < ndb; ++i) sc.seqs[(size_t)ndb + i] = db[(size_t)ndb - 1 - i];
+        sc.motifs.resize(2 * (size_t)m);
+        for (int32_t i = 0; i < m; ++i) { sc.motifs[i] = motif[i]; sc.motifs[(size_t)m + i] = motif[m - 1 - i]; }
+        sc.seq_off[0] = 0; sc.seq_off[1] = ndb; sc.seq_off[2] = 2 * (int64_t)ndb;
+        sc.nfl[0] = nfl; sc.ntr[0] = ntr; sc.nfr[0] = nfr;
+        sc.nfl[1] = nfr; sc.ntr[1] = ntr; sc.nfr[1] = nfl;   // reversed window: the right flank leads
+        sc.read_off[0] = 0; sc.read_off[1] = 1; sc.read_off[2] = 2;
+        sc.motif_off[0] = 0; sc.motif_off[1] = m; sc.motif_off[2] = 2 * m;
+
+        // dicts in insertion order (repeats.py:103-104); fwd and rev are always filled together (:123-128)
+        std::vector<int64_t> key;
+        std::vector<int32_t> fs, fa, rs, ra;
+        auto find_key = [&](int64_t i) {
+            for (size_t k = 0; k < key.size(); ++k)
+                if (key[k] == i) return (int)k;
+            return -1;
+        };
+        int64_t st_size[4];
+        int32_t st_dir[4];
+        int sp = 0;
+        st_size[sp] = (int64_t)start_count - step; st_dir[sp++] = -1;   // :100-101
+        st_size[sp] = (int64_t)start_count + step; st_dir[sp++] = 1;
+        st_size[sp] = start_count;                 st_dir[sp++] = 0;
+        const bool widen = step > lsr;
+        while (sp > 0 && n_off < max_iters) {                                // :106
+            --sp;
+            const int64_t size = st_size[sp];
+            const int32_t dir = st_dir[sp];
+            if (size < 0) continue;                                          // :108-109
+            int64_t w_lo = size - ((dir < 1 || widen) ? lsr : 0);            // :114-117
+            if (w_lo < 0) w_lo = 0;
+            const int64_t w_hi = size + ((dir > -1 || widen) ? lsr : 0);
+            int rc = sc.ensure(w_lo, w_hi);
+            if (rc) return rc;
+            for (int64_t i = w_lo; i <= w_hi; ++i) {                         // :119-130
+                if (find_key(i) >= 0) continue;
+                const auto& v = sc.vals[(size_t)sc.find(i)];
+                key.push_back(i);
+                fs.push_back(v[0]); fa.push_back(v[1] + 1 - nfl - ref_size);   // :34
+                rs.push_back(v[2]); ra.push_back(v[3] + 1 - nfr - ref_size);   // :41
+                ++n_off;
+            }
+            // mv = max((*fwd_scores, *rev_scores), key=(score, adj)): first maximum of the concatenation (:135)
+            bool have = false;
+            int64_t mv_i = 0;
+            int32_t mv_s = 0, mv_a = 0;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int64_t i = w_lo; i <= w_hi; ++i) {
+                    const int at = find_key(i);
+                    const int32_t s = pass == 0 ? fs[(size_t)at] : rs[(size_t)at];
+                    const int32_t ad = pass == 0 ? fa[(size_t)at] : ra[(size_t)at];
+                    if (!have || s > mv_s || (s == mv_s && ad > mv_a)) { have = true; mv_i = i; mv_s = s; mv_a = ad; }
+                }
+            if (mv_i > size && find_key(mv_i + step) < 0 && mv_i + step >= 0) { st_size[sp] = mv_i + step; st_dir[sp++] = 1; }    // :136-143
+            if (mv_i < size && find_key(mv_i - step) < 0 && mv_i - step >= 0) { st_size[sp] = mv_i - step; st_dir[sp++] = -1; }  // :144-151
+        }
+        if (key.empty()) return fail(STRK_E_EMPTY, "max() arg is an empty sequence: no reference boundary could be scored");
+        size_t bf = 0, br = 0;                                               // :154-156 first maxima by score
+        for (size_t k = 1; k < key.size(); ++k) {
+            if (fs[k] > fs[bf]) bf = k;
+            if (rs[k] > rs[br]) br = k;
+        }
+        l_offset = ra[br];                                                   // :161-162
+        r_offset = fa[bf];
+        if (l_offset >= nfl - vcf_anchor_size) l_offset = 0;                 // :164-169
+        if (r_offset >= nfr) r_offset = 0;
+    }
+    const int32_t lo_pos = l_offset > 0 ? l_offset : 0, ro_pos = r_offset > 0 ? r_offset : 0;   // :171-176
+    const int32_t nfl2 = nfl - lo_pos, ntr2 = ntr + lo_pos + ro_pos, nfr2 = nfr - ro_pos;
+    if (nfl2 < 0 || nfr2 < 0) return fail(STRK_E_INVALID, "boundary offsets exceed the flanks");
+    // round(((start * motif_size) + max(0, l) + max(0, r)) / motif_size): true division, round-half-even (:182)
+    const int32_t start2 = (int32_t)__builtin_rint((double)((int64_t)start_count * m + lo_pos + ro_pos) / (double)m);
+    int32_t cn = 0, score = 0, n_final = 0;
+    const int rc = strk_repeat_count(ctx, start2, db.data() + nfl2, ntr2, db.data(), nfl2, db.data() + nfl2 + ntr2, nfr2,
+                                     motif, m, max_iters, lsr, step, &cn, &score, &n_final);
+    if (rc) return rc;
+    out9[0] = cn; out9[1] = score; out9[2] = l_offset; out9[3] = r_offset; out9[4] = n_off; out9[5] = n_final;
+    out9[6] = nfl2; out9[7] = ntr2; out9[8] = nfr2;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -581,46 +794,27 @@ int strk_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int
 int strk_score_table(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, const int32_t* n,
                      const int64_t* table_off, int32_t end_flags, int32_t force_generic, int32_t* scores,
                      strk_stats* stats) {
+    return score_table_impl(ctx, batch, lo, n, table_off, end_flags, force_generic, 0, scores, nullptr, stats);
+}
+
+int strk_score_ref_table(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, const int32_t* n,
+                         const int64_t* table_off, int32_t force_generic, int32_t* scores, int32_t* end_query,
+                         strk_stats* stats) {
+    if (!end_query) return fail(STRK_E_INVALID, "end_query is NULL");
+    return score_table_impl(ctx, batch, lo, n, table_off, STRK_DB_END_FREE, force_generic, 1, scores, end_query, stats);
+}
+
+int strk_ref_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int32_t tr_len, const uint8_t* fl,
+                          int32_t fl_len, const uint8_t* fr, int32_t fr_len, const uint8_t* motif, int32_t motif_len,
+                          int32_t ref_size, int32_t vcf_anchor_size, int32_t max_iters, int32_t local_search_range,
+                          int32_t step_size, int32_t respect_coords, int32_t* out9) {
     if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
-    if (stats) memset(stats, 0, sizeof *stats);
-    if (end_flags < 0 || end_flags > 15) return fail(STRK_E_INVALID, "bad end_flags");
-    strk_batch d;
-    int rc;
-    if ((rc = upload_batch(ctx, batch, &d, nullptr))) return rc;
-    if (batch->n_reads == 0 || batch->n_loci == 0) return 0;
-    if (!lo || !n || !table_off || !scores) return fail(STRK_E_INVALID, "lo / n / table_off / scores is NULL");
-    const size_t nr = (size_t)batch->n_reads;
-    size_t n_chunks = 0;
-    for (size_t r = 0; r < nr; ++r) {
-        if (lo[r] < 0 || n[r] < 0) return fail(STRK_E_INVALID, "read %zu: negative window", r);
-        if (table_off[r + 1] - table_off[r] < n[r] || table_off[r] < 0) return fail(STRK_E_INVALID, "read %zu: table_off too small", r);
-        n_chunks += ((size_t)n[r] + kTableMax - 1) / kTableMax;
-    }
-    const size_t tab = (size_t)table_off[nr];
-    if ((rc = ensure_workspace(ctx, batch->n_reads, batch->n_loci, tab, std::max<size_t>(n_chunks, 1)))) return rc;
-    KArgs a = make_args(ctx, &d, end_flags, 0, 0, (int)std::max<size_t>(n_chunks, 1), nullptr);
-    hipStream_t st = nullptr;
-    HIP_TRY(hipMemcpyAsync(a.win_lo, lo, nr * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(a.win_n, n, nr * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(a.tab_off, table_off, nr * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, kCountersBytes, st));
-    HIP_TRY(hipEventRecord(ctx->ev[0], st));
-    enqueue_scoring(ctx, a, 1, nullptr, batch->n_reads, force_generic, st, true);
-    HIP_TRY(hipEventRecord(ctx->ev[3], st));
-    HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipGetLastError());
-    if ((rc = check_error_bits(ctx->h_counters[kCntError]))) return rc;
-    if (tab) HIP_TRY(hipMemcpy(scores, a.table, tab * 4, hipMemcpyDeviceToHost));
-    if (stats) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) stats->kernel_ms = ms;
-        if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) stats->dp_kernel_ms = ms;
-        stats->n_dp_launches = 2;
-        stats->n_fallback = ctx->h_counters[kCntClass0 + kGenericClass];
-        stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->h_counters) + kCellsOff);
-    }
-    return 0;
+    if (!out9) return fail(STRK_E_INVALID, "out9 is NULL");
+    if (tr_len < 0 || fl_len < 0 || fr_len < 0 || motif_len < 1) return fail(STRK_E_INVALID, "bad sequence length");
+    if ((tr_len && !tr) || (fl_len && !fl) || (fr_len && !fr) || !motif) return fail(STRK_E_INVALID, "sequence pointer is NULL");
+    if (local_search_range < 0 || step_size < 1) return fail(STRK_E_INVALID, "local_search_range must be >= 0 and step_size >= 1");
+    return ref_repeat_count_impl(ctx, start_count, tr, tr_len, fl, fl_len, fr, fr_len, motif, motif_len, ref_size,
+                                 vcf_anchor_size, max_iters, local_search_range, step_size, respect_coords, out9);
 }
 
 }  // extern "C"

@@ -77,6 +77,8 @@ struct KArgs {
     int32_t window;       // half width (plan kernel)
     int32_t table_stride; // entries per read (plan kernel)
     int32_t max_iters, lsr, step, tie_last;  // search parameters (speculative search in k_dp_all)
+    int32_t ref_mode;     // 1: reference-side scoring (repeats.py:23-43): candidate = fl + motif*i only, the
+                          //    table holds (score, end_query) pairs, end_flags must be STRK_DB_END_FREE
 };
 
 enum Counter {
@@ -95,11 +97,11 @@ constexpr int kSpecMiss = 1, kSpecEmpty = 2;
 // ---------------------------------------------------------------------------------------------
 // Plan: per read -> locus id, candidate window, table slot, kernel class.
 // ---------------------------------------------------------------------------------------------
-__device__ inline int classify(int nfl, int ntr, int nfr, int m, int lo, int n, int force_generic) {
+__device__ inline int classify(int nfl, int ntr, int nfr, int m, int lo, int n, int force_generic, int ref_mode) {
     const long long ndb = (long long)nfl + ntr + nfr;
     const long long rows = (long long)nfl + (long long)(lo + n - 1) * m;
-    if (force_generic || nfl < 1 || nfr < 1 || n > kTableMax || m > kMotifMax) return kGenericClass;
-    for (int c = 0; c < kNumClasses; ++c) {
+    if (force_generic || nfl < 1 || (nfr < 1 && !ref_mode) || n > kTableMax || m > kMotifMax) return kGenericClass;
+    for (int c = ref_mode ? kNumClasses - 1 : 0; c < kNumClasses; ++c) {  // ref mode: one specialisation (the widest class)
         const int cap = class_cap(c);
         if (ndb + 1 <= cap && rows <= cap + kRowSlack) return c;
     }
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     const unsigned long long ndb = (unsigned long long)nfl + ntr + nfr;
     for (int k0 = 0; k0 < n; k0 += kTableMax) {
         const int nn = min(kTableMax, n - k0);
-        const int c = classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic);
+        const int c = classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic, a.ref_mode);
         atomicAdd(&s_cnt[c], 1);
         if (c == kGenericClass) {
             for (int k = 0; k < nn; ++k) cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + k) * m + nfr);
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     __syncthreads();
     for (int k0 = 0; k0 < n; k0 += kTableMax) {
         const int nn = min(kTableMax, n - k0);
-        const int c = classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic);
+        const int c = classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic, a.ref_mode);
         const int idx = s_base[c] + atomicAdd(&s_cnt[c], 1);
         if (idx < a.list_stride) {
             a.cls_list[(size_t)c * a.list_stride * 2 + 2 * idx] = r;
@@ -446,11 +448,69 @@ __device__ __forceinline__ void fwd_pass(const PassCtx& x, int rowsP, const uint
 #undef STRK_FSTEP
 }
 
+// Reference-side forward pass (score_ref_boundaries, strkit/call/repeats.py:23-43): the candidate is
+// fl + motif*i with NO right flank, the db end is free, and both the score and the db position where
+// the alignment ends (parasail's end_query) are wanted.  At fork row R_k every slot j >= 1 offers
+// H(R_k, j) = G - g*(R_k + j); the fold keeps (value, smallest j) as one 64-bit key
+// ((G + g*(ndb - j)) << 20 | (2^20 - 1 - j)) with an LDS 64-bit atomic max.  One instance (G = 64,
+// CL = 28) serves every shape: this path runs once per locus, not once per read.
+template <int NQ, int G>
+__device__ __forceinline__ void fwd_pass_ref(const PassCtx& x, int rowsP, const uint8_t* cp, int nEff, int fork0, int m,
+                                             unsigned long long* comb64) {
+    constexpr int g = kGap, CL = 4 * NQ;
+    int Ha[CL], Hb[CL];
+    unsigned sel[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sel[q] = x.act ? __builtin_amdgcn_alignbyte(x.selw[q + 1], x.selw[q], 3) : 0x0c0c0c0cu;
+#pragma unroll
+    for (int c = 0; c < CL; ++c) Ha[c] = x.dbBeg ? g * min(x.lig * CL + c, x.ndb) : 0;
+    const int Tf = (wave_max_over_groups(nEff > 0 ? rowsP + G - 1 : 0) + 1) & ~1;
+    const int bstep = x.cBeg ? g : 0;
+    const int gm = g * m;
+    int hout = Ha[CL - 1];
+    int edgePrev = from_left<G>(0, hout, x.first);
+    int gr = -g * x.lig;
+    int forkG = nEff > 0 ? g * fork0 : 0x7fffffff;
+    int forkIdx = 0;
+    const uint8_t* pa = cp + (G - 1) - x.lig;
+    uint2 wordNext = x.tbl[pa[0]];
+    unsigned symNext = pa[1];
+#define STRK_RSTEP(SRC, DST, T)                                                              \
+    {                                                                                        \
+        const uint2 word = wordNext;                                                         \
+        wordNext = x.tbl[symNext];                                                           \
+        symNext = pa[(T) + 2];                                                               \
+        const int edge = from_left<G>(bstep * ((T) + 1), hout, x.first);                     \
+        hout = dp_row<NQ, true>(SRC, DST, sel, word, edge, edgePrev);                        \
+        edgePrev = edge;                                                                     \
+        gr += g;                                                                             \
+        if (gr == forkG) {                                                                   \
+            unsigned long long acc = 0;                                                      \
+            _Pragma("unroll") for (int c = 0; c < CL; ++c) {                                 \
+                const int s = x.lig * CL + c;                                                \
+                const int j = min(s, x.ndb);                                                 \
+                const unsigned long long key = ((unsigned long long)(unsigned)(DST[c] + g * (x.ndb - j)) << 20) | \
+                                               (unsigned long long)(0xFFFFF - j);            \
+                if (s >= 1) acc = key > acc ? key : acc;                                     \
+            }                                                                                \
+            atomicMax(&comb64[forkIdx], acc);                                                \
+            ++forkIdx;                                                                       \
+            forkG = forkIdx < nEff ? forkG + gm : 0x7fffffff;                                \
+        }                                                                                    \
+    }
+    for (int t = 0; t < Tf; t += 2) {
+        STRK_RSTEP(Ha, Hb, t)
+        STRK_RSTEP(Hb, Ha, t + 1)
+    }
+#undef STRK_RSTEP
+}
+
 // Processes the items [base, base + 64/G) of class list `cls`, one per group of G lanes of this
 // wave.  G (16/32/64) and CL (columns per lane) are wave-uniform run-time values: set-up and
 // epilogue are one body, only the two hot loops are specialised on CL/4 (six copies each).
 // `ap` points at the kernel's KArgs in the kernarg segment: fields are scalar-loaded where they are
 // used instead of living in SGPRs across the hot loops.
+template <bool REF>
 __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint8_t* Lw, const uint8_t* s_enc,
                                         const int8_t* s_mat) {
     constexpr int g = kGap;
@@ -494,7 +554,8 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     }
     const int ndb = nfl + ntr + nfr;
     const int rowsP = act ? nfl + (lo + n - 1) * m : 0;
-    const int rowsT = act ? nfr : 0;
+    constexpr int ref_mode = REF ? 1 : 0;   // k_dp_ref (reference side) / k_dp_all (reads)
+    const int rowsT = (act && !ref_mode) ? nfr : 0;
 
     // ---- stage the encoded read window and collect its symbol set ------------------------------
     uint8_t* const motifL = Lg + lay.off_b0;   // encoded motif; the area is free until the backward pass ends
@@ -560,7 +621,10 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
         }
         tbl[e] = make_uint2(wlo, whi);
     }
-    for (int e = lig; e < kTableMax; e += G) { comb[e] = kNegInf; lmaxA[e] = kNegInf; }
+    for (int e = lig; e < kTableMax; e += G) {   // ref mode reuses the two arrays as 32 x u64 keys (0 = empty)
+        comb[e] = ref_mode ? 0 : kNegInf;
+        lmaxA[e] = ref_mode ? 0 : kNegInf;
+    }
     // ---- candidate row symbols: null padding | fl | motif*i_hi | null padding ------------------
     {
         const int lenP = rowsP + 2 * (G - 1) + 4;
@@ -616,6 +680,9 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
         if (first) misc[1] = zsave;                                      \
         fwd_pass<NQ_, G_>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA);     \
     }
+    if constexpr (REF) {
+        fwd_pass_ref<7, 64>(x, rowsP, cp, nEff, fork0, m, reinterpret_cast<unsigned long long*>(comb));
+    } else
     switch (cls) {
     case 0: STRK_PASSES(2, 16) break;
     case 1: STRK_PASSES(3, 16) break;
@@ -637,7 +704,16 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     // ---- assemble S[lo + k] (fields re-read from the kernarg segment: nothing was kept live) -----
     KArgsKernarg ap2 = ap;
     asm volatile("" : "+s"(ap2));
-    if (act) {
+    if (act && ref_mode) {
+        const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(comb);
+        int32_t* const out = ap2->table + ap2->tab_off[r] + 2 * k0;
+        for (int k = lig; k < n; k += G) {
+            const unsigned long long key = keys[k];
+            const int R = nfl + (lo + k) * m;
+            out[2 * k] = (int)(key >> 20) - g * ndb - g * R;          // score
+            out[2 * k + 1] = (0xFFFFF - (int)(key & 0xFFFFF)) - 1;    // end_query: last aligned db index
+        }
+    } else if (act) {
         const int zfree = misc[1] - g * ndb;
         int32_t* const out = ap2->table + ap2->tab_off[r] + k0;
         for (int k = lig; k < n; k += G) {
@@ -652,7 +728,7 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     wave_lds_sync();
     // ---- speculative search for start == est_cn (the no-feedback guess), replayed from LDS --------
     int4* const spec = ap2->spec;
-    if (spec && act && first && k0 == 0) {
+    if (spec && !ref_mode && act && first && k0 == 0) {
         SeenMask64 seen;
         const SearchResult res = search_replay(ap2->est_cn[r], ap2->step, ap2->lsr, ap2->max_iters, ap2->tie_last, comb, lo, n, seen);
         spec[r] = make_int4(res.cn, res.score, res.n_explored, (res.miss ? kSpecMiss : 0) | (res.empty ? kSpecEmpty : 0));
@@ -662,9 +738,8 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
 static_assert(kCLMax == 28 && kNumClasses == 14 && class_CL(0) == 8 && class_CL(6) == 16 && class_CL(10) == 16,
               "dp_wave dispatches the 14 (CL/4, G) classes by index");
 
-// All fast classes in ONE launch: every wave pulls chunks (one item per group) from a device-side
-// queue, most expensive classes first.
-__global__ void __launch_bounds__(256) k_dp_all(KArgs a_by_value) {
+template <bool REF>
+__device__ __forceinline__ void dp_kernel_body() {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * kWaveLdsBytes + kLdsSlack];
     __shared__ uint8_t s_enc[256];
     __shared__ int8_t s_mat[kNSym * kNSym + 3];
@@ -673,7 +748,6 @@ __global__ void __launch_bounds__(256) k_dp_all(KArgs a_by_value) {
     __syncthreads();
     uint8_t* const Lw = lds + (threadIdx.x >> 6) * kWaveLdsBytes;
     const KArgsKernarg kernarg = (KArgsKernarg)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)a_by_value;
     for (;;) {
         KArgsKernarg ap = kernarg;
         asm volatile("" : "+s"(ap));
@@ -691,8 +765,23 @@ __global__ void __launch_bounds__(256) k_dp_all(KArgs a_by_value) {
             acc += nch;
         }
         if (cls < 0) break;
-        dp_wave(ap, cls, base, Lw, s_enc, s_mat);
+        dp_wave<REF>(ap, cls, base, Lw, s_enc, s_mat);
     }
+}
+
+// All fast classes in ONE launch: every wave pulls chunks (one item per group) from a device-side
+// queue, most expensive classes first.  KArgs must be the kernel's only argument (dp_wave reads it
+// through the kernarg segment pointer).
+__global__ void __launch_bounds__(256) k_dp_all(KArgs a_by_value) {
+    (void)a_by_value;
+    dp_kernel_body<false>();
+}
+
+// Reference-side scoring (get_ref_repeat_count, once per locus): same set-up, forward pass only,
+// (score, end_query) pairs.
+__global__ void __launch_bounds__(256) k_dp_ref(KArgs a_by_value) {
+    (void)a_by_value;
+    dp_kernel_body<true>();
 }
 static_assert(class_CL(kNumClasses - 1) <= kCLMax && class_CL(5) <= kCLMax && class_CL(9) <= kCLMax, "kCLMax covers every class");
 
@@ -719,14 +808,20 @@ __global__ void k_dp_generic(KArgs a) {
         const int m = a.motif_off[l + 1] - a.motif_off[l];
         const uint8_t* db = a.seqs + a.seq_off[r];
         const int ndb = nfl + ntr + nfr;
-        const long long ncand = (long long)nfl + (long long)i * m + nfr;
-        int32_t* out = a.table + a.tab_off[r] + k0 + k;
-        if (ndb <= 0 || ncand <= 0) { *out = 0; continue; }
+        const int ncfr = a.ref_mode ? 0 : nfr;   // the reference-side candidate has no right flank
+        const long long ncand = (long long)nfl + (long long)i * m + ncfr;
+        int32_t* out = a.ref_mode ? a.table + a.tab_off[r] + 2 * (k0 + k) : a.table + a.tab_off[r] + k0 + k;
+        if (ndb <= 0 || ncand <= 0) {
+            out[0] = 0;
+            if (a.ref_mode) out[1] = -1;
+            continue;
+        }
         const unsigned long long need = (unsigned long long)ndb + 1;
         const unsigned long long at = atomicAdd(a.scratch_used, need);
         if (at + need > (unsigned long long)a.scratch_cap) {
             atomicOr(&a.counters[kCntError], kErrScratch);
-            *out = 0;
+            out[0] = 0;
+            if (a.ref_mode) out[1] = -1;
             continue;
         }
         int32_t* Hrow = a.scratch + at;
@@ -750,10 +845,13 @@ __global__ void k_dp_generic(KArgs a) {
             }
             lastcol = max(lastcol, left);
         }
-        int best = Hrow[ndb];
+        int best = Hrow[ndb], bestj = ndb;
         if (cEnd) best = max(best, lastcol);
-        if (dbEnd) for (int j = 1; j <= ndb; ++j) best = max(best, Hrow[j]);
-        *out = best;
+        if (dbEnd)
+            for (int j = 1; j <= ndb; ++j)
+                if (Hrow[j] > best || (Hrow[j] == best && j < bestj && !cEnd)) { best = Hrow[j]; bestj = j; }
+        out[0] = best;
+        if (a.ref_mode) out[1] = bestj - 1;
     }
 }
 

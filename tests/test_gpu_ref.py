@@ -1,0 +1,78 @@
+"""GPU parity of the reference-side path (get_ref_repeat_count / score_ref_boundaries) vs the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import ALPHA_ACGT, ALPHA_WC, rand_seq, random_locus
+from strkit_amd.repeat_count_params import RepeatCountParams, get_reference_rc_params
+from strkit_amd.synth import LocusBatch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_batch(loci):
+    """Two device reads per locus: the window and its reversal with the flanks swapped."""
+    out = []
+    for motif, (fl, tr, fr) in loci:
+        out.append((motif, [(fl, tr, fr)]))
+        out.append((motif[::-1], [(fr[::-1], tr[::-1], fl[::-1])]))
+    return LocusBatch.from_reads(out)
+
+
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_score_ref_boundaries(gpu_ctx, force_generic):
+    from strkit_amd.batch import score_ref_table
+    rng = np.random.default_rng(31)
+    loci = []
+    for _ in range(40):
+        motif, reads = random_locus(rng, 1, motif_len=(1, 7), cn=(1, 30), flank=(10, 70), alpha=ALPHA_WC, edits=(0, 5))
+        loci.append((motif, reads[0]))
+    b = _ref_batch(loci)
+    lo = np.maximum(0, np.repeat([max(0, round(len(t[1]) / len(m)) - 4) for m, t in loci], 2)).astype(np.int32)
+    n = np.full(b.n_reads, 9, np.int32)
+    got = score_ref_table(b, lo, n, force_generic=force_generic, ctx=gpu_ctx)
+    for k, (motif, (fl, tr, fr)) in enumerate(loci):
+        db = fl + tr + fr
+        ref_size = len(tr)
+        for j in range(9):
+            i = int(lo[2 * k]) + j
+            (fs, fa), (rs, ra) = oracle.score_ref_boundaries(db, fl, fr, motif, i, ref_size)
+            g_fs, g_fe = int(got[2 * k][0][j]), int(got[2 * k][1][j])
+            g_rs, g_re = int(got[2 * k + 1][0][j]), int(got[2 * k + 1][1][j])
+            assert (g_fs, g_fe + 1 - len(fl) - ref_size) == (fs, fa), (k, i, "fwd")
+            assert (g_rs, g_re + 1 - len(fr) - ref_size) == (rs, ra), (k, i, "rev")
+
+
+def test_get_ref_repeat_count_matches_oracle(gpu_ctx):
+    from strkit_amd.repeats import get_ref_repeat_count
+    rng = np.random.default_rng(32)
+    for it in range(60):
+        motif = rand_seq(rng, int(rng.integers(1, 7)))
+        cn = int(rng.integers(2, 40))
+        ext_l, ext_r = int(rng.integers(0, 4)), int(rng.integers(0, 4))  # repeat copies hidden in the flanks
+        fl = rand_seq(rng, int(rng.integers(20, 70))) + motif * ext_l
+        fr = motif * ext_r + rand_seq(rng, int(rng.integers(20, 70)))
+        tr = motif * cn
+        if it % 3 == 0:  # soft-masked lower case reference and an imperfect tract
+            tr = tr[: len(tr) // 2].lower() + ("A" if tr[len(tr) // 2:len(tr) // 2 + 1] != "A" else "C") + tr[len(tr) // 2 + 1:]
+        start = round(len(tr) / len(motif)) + int(rng.integers(-2, 3))
+        rc = RepeatCountParams("repalign", 250, 3, 1)
+        for respect in (False, True):
+            exp = oracle.ref_repeat_count(start, tr, fl, fr, motif, len(tr), 5, rc.max_iters, 3, 1, respect_coords=respect)
+            got = get_ref_repeat_count(start, tr, fl, fr, motif, len(tr), 5, rc, respect_coords=respect)
+            assert got == exp, (it, respect, motif, fl, tr, fr)
+
+
+def test_ref_schedule_with_big_steps(gpu_ctx):
+    """Large reference copy numbers search in bigger steps (repeat_count_params.py:17-42)."""
+    from strkit_amd.repeats import get_ref_repeat_count
+    rng = np.random.default_rng(33)
+    for cn, est in ((230, 226), (60, 64)):
+        motif = "CAG"
+        fl, fr = rand_seq(rng, 50, ALPHA_ACGT) + "CAGCAG", "CAG" + rand_seq(rng, 50, ALPHA_ACGT)
+        tr = motif * cn
+        rc = get_reference_rc_params("repalign", est, 250)
+        exp = oracle.ref_repeat_count(est, tr, fl, fr, motif, len(tr), 5, rc.max_iters, rc.initial_local_search_range,
+                                      rc.initial_step_size)
+        got = get_ref_repeat_count(est, tr, fl, fr, motif, len(tr), 5, rc)
+        assert got == exp
