@@ -96,7 +96,12 @@ namespace {
 using namespace strk;
 
 constexpr int kDefaultWindow = 8;
-constexpr size_t kScratchInts = (size_t)16 << 20;  // 64 MiB of int32 rows for the generic kernel
+// Scratch pool (int32 units): kLongWaves slots of kLongSlotInts for k_dp_long (one per resident wave; a slot
+// holds the backward row of all column tiles + two boundary columns: windows up to ~40 kb), then 16 Mi
+// ints of H rows for the generic kernel.  256 MiB of the 288 GB, allocated once per context.
+constexpr int kLongBlocks = 128, kLongWaves = kLongBlocks * 4;
+constexpr size_t kLongSlotInts = (size_t)96 << 10;
+constexpr size_t kScratchInts = kLongWaves * kLongSlotInts + ((size_t)16 << 20);
 // device layout of the `counters` buffer: int32[kCntTotal] | pad | u64 cells | u64 scratch_used
 constexpr size_t kCellsOff = 64 * sizeof(int32_t);
 constexpr size_t kCountersBytes = kCellsOff + 2 * sizeof(unsigned long long);
@@ -122,7 +127,7 @@ int ensure_workspace(strk_ctx* c, int n_reads, int n_loci, size_t table_ints, si
     if ((rc = c->win_n.ensure(nr * 4))) return rc;
     if ((rc = c->tab_off.ensure(nr * 8))) return rc;
     if ((rc = c->table.ensure(std::max<size_t>(table_ints, 1) * 4))) return rc;
-    if ((rc = c->cls_list.ensure((size_t)(kNumClasses + 1) * std::max<size_t>(n_items, 1) * 2 * 4))) return rc;
+    if ((rc = c->cls_list.ensure((size_t)kNumLists * std::max<size_t>(n_items, 1) * 2 * 4))) return rc;
     if ((rc = c->counters.ensure(kCountersBytes))) return rc;
     if ((rc = c->state_i32.ensure(nl * 3 * 4))) return rc;
     if ((rc = c->state_f64.ensure(nl * 8))) return rc;
@@ -154,6 +159,8 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
     a.scratch_used = a.cells + 1;
     a.scratch = c->scratch.as<int32_t>();
     a.scratch_cap = (long long)c->scratch_ints;
+    a.long_slot = (long long)kLongSlotInts;
+    a.long_waves = kLongWaves;
     a.list_stride = list_stride;
     a.end_flags = end_flags;
     a.window = window;
@@ -179,6 +186,7 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
         if (a.ref_mode) hipLaunchKernelGGL(k_dp_ref, dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);
     }
+    if (!force_generic && !a.ref_mode) hipLaunchKernelGGL(k_dp_long, dim3(kLongBlocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dp_generic, dim3(256), dim3(256), 0, st, a);
     if (time_dp) (void)hipEventRecord(c->ev[2], st);
 }
@@ -258,7 +266,7 @@ int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs
         if ((rc = c->tab_off2.ensure((size_t)nr * 8))) return rc;
         if ((rc = c->table2.ensure(tab2 * 4))) return rc;
         if ((rc = c->items.ensure(items.size() * 4))) return rc;
-        if ((rc = c->cls_list.ensure((size_t)(kNumClasses + 1) * n_chunks * 2 * 4))) return rc;
+        if ((rc = c->cls_list.ensure((size_t)kNumLists * n_chunks * 2 * 4))) return rc;
         HIP_TRY(hipMemcpyAsync(c->win_lo2.p, w_lo.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(c->win_n2.p, w_n.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(c->tab_off2.p, w_off.data(), (size_t)nr * 8, hipMemcpyHostToDevice, st));

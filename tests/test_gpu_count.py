@@ -103,3 +103,12 @@ def test_identical_reads_share_one_table(gpu_ctx):
     assert st2["n_dedup_reads"] == 0 and st2["dp_cells"] > st["dp_cells"]
     got3, _ = _run(b, gpu_ctx, window=1)  # copies through the miss path too
     _compare(b, got3, exp)
+
+
+def test_expansion_stress_long_reads(gpu_ctx):
+    """BASELINE config 5 shape (motif 1-6, hundreds of copies): windows of several kb through k_dp_long."""
+    b = make_config(5, n_loci=3, reads_per_locus=4, cn_range=(400, 900))
+    assert (b.nfl + b.ntr + b.nfr).max() > 1792
+    got, st = _run(b, gpu_ctx)
+    _compare(b, got, oracle_count(b))
+    assert st["n_fallback"] == 0

@@ -100,3 +100,24 @@ def test_lowercase_and_unknown_bytes(gpu_ctx):
     loci = [("cag", [("acgtACGT" * 3, "cagCAGcag" * 3, "ttgacc" * 4), ("ACGT?ACGT", "CAG-CAG", "TTGA.CC")])]
     b = LocusBatch.from_reads(loci)
     _check(b, np.array([0, 0], np.int32), np.array([14, 6], np.int32), ctx=gpu_ctx)
+
+
+def test_long_windows_use_the_tiled_kernel(gpu_ctx):
+    """|db| beyond the widest fast class (1 792 slots): k_dp_long tiles the columns; 1, 2 and 3 tiles."""
+    rng = np.random.default_rng(15)
+    loci = []
+    for cn, m in ((450, 4), (900, 3), (700, 6), (2400, 1), (1300, 2)):
+        motif = rand_seq(rng, m)
+        from helpers import noisy_tract
+        fl, fr = rand_seq(rng, 70), rand_seq(rng, 70)
+        reads = [(fl, noisy_tract(rng, motif, cn + int(rng.integers(-2, 3)), int(rng.integers(0, 9)), ALPHA_WC), fr)
+                 for _ in range(2)]
+        loci.append((motif, reads))
+    b = LocusBatch.from_reads(loci)
+    assert (b.nfl + b.ntr + b.nfr).min() > 1792
+    lo = np.maximum(0, b.est_cn - 2).astype(np.int32)
+    n = np.full(b.n_reads, 5, np.int32)
+    st = _check(b, lo, n, ctx=gpu_ctx)
+    assert st["n_fallback"] == 0
+    _check(b, lo, n, 0, ctx=gpu_ctx)
+    _check(b, lo, n, 6, ctx=gpu_ctx)
