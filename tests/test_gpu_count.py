@@ -107,7 +107,7 @@ def test_identical_reads_share_one_table(gpu_ctx):
 
 def test_expansion_stress_long_reads(gpu_ctx):
     """BASELINE config 5 shape (motif 1-6, hundreds of copies): windows of several kb through k_dp_long."""
-    b = make_config(5, n_loci=3, reads_per_locus=4, cn_range=(400, 900))
+    b = make_config(5, n_loci=3, reads_per_locus=4, cn_range=(700, 1100), motif_len=(3, 6))
     assert (b.nfl + b.ntr + b.nfr).max() > 1792
     got, st = _run(b, gpu_ctx)
     _compare(b, got, oracle_count(b))
