@@ -85,6 +85,7 @@ def main() -> None:
     ap.add_argument("--pipeline", type=int, default=3, help="batched calls in flight (contexts/streams)")
     ap.add_argument("--cpu-sample-loci", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (self-test)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,7 +108,10 @@ def main() -> None:
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- this rank's shard: its own loci (weak scaling), inputs made resident in HBM -----------
@@ -127,12 +131,12 @@ def main() -> None:
     ctxs = [_lib.Context(local_rank) for _ in range(D)]
     streams = [torch.cuda.Stream(dev) for _ in range(D)]
     outs = [torch.zeros((4, b.n_reads), dtype=torch.int32, device=dev) for _ in range(D)]  # cn | score | n_iters | start
-    gathered = [torch.zeros((world * 4, b.n_reads), dtype=torch.int32, device=dev) for _ in range(D)] if world > 1 else None
+    gathered = [torch.zeros((world * 4, b.n_reads), dtype=torch.int32, device=dev) for _ in range(D)] if use_dist else None
     acc = dict(dp_ms=0.0, all_ms=0.0, misses=0, fallback=0, dedup=0, n=0)
 
     def submit(i):
         k = i % D
-        if world > 1:
+        if use_dist:
             streams[k].wait_stream(torch.cuda.current_stream(dev))  # the previous gather of this slot has read outs[k]
         o = outs[k]
         _lib.check(L.strk_submit_loci_device(ctxs[k].handle, C.byref(sb), C.byref(p), o[0].data_ptr(), o[1].data_ptr(),
@@ -145,7 +149,7 @@ def main() -> None:
             acc["dp_ms"] += st.dp_kernel_ms; acc["all_ms"] += st.kernel_ms
             acc["misses"] += st.n_miss_reads; acc["fallback"] += st.n_fallback; acc["dedup"] += st.n_dedup_reads
             acc["n"] += 1
-        if world > 1:  # collect per-read results of every shard (RCCL all-gather over xGMI)
+        if use_dist:  # collect per-read results of every shard (RCCL all-gather over xGMI)
             dist.all_gather_into_tensor(gathered[k], outs[k])
 
     def run(n_steps, timed):
@@ -158,7 +162,7 @@ def main() -> None:
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -170,7 +174,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     dp_ms, all_ms, misses, fallback = acc["dp_ms"], acc["all_ms"], acc["misses"], acc["fallback"]
     out = outs[(a.steps - 1) % D]
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -221,7 +225,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": WORKLOAD if a.config == 2 and a.loci is None else f"cfg{a.config}, {b.n_loci} loci per GPU",
                        "loci_per_gpu": b.n_loci, "reads_per_gpu": b.n_reads, "window": int(p.window) or 8,
-                       "parallelism": f"loci-sharded x{a.gpus}" + (" + all_gather" if world > 1 else ""),
+                       "parallelism": f"loci-sharded x{a.gpus}" + (" + all_gather" if use_dist else ""),
                        "calls_in_flight": D},
             "loci_per_s": n_loci_all * a.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": alg_bytes / dp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -240,7 +244,9 @@ def main() -> None:
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
+        if rank == 0 and not torch.equal(gathered[(a.steps - 1) % D][:4], out):
+            sys.exit("all_gather self-check failed")
         dist.destroy_process_group()
     for c in ctxs:
         c.close()
