@@ -97,10 +97,10 @@ using namespace strk;
 
 constexpr int kDefaultWindow = 8;
 // Scratch pool (int32 units): kLongWaves slots of kLongSlotInts for k_dp_long (one per resident wave; a slot
-// holds the backward row of all column tiles + two boundary columns: windows up to ~40 kb), then 16 Mi
-// ints of H rows for the generic kernel.  256 MiB of the 288 GB, allocated once per context.
-constexpr int kLongBlocks = 128, kLongWaves = kLongBlocks * 4;
-constexpr size_t kLongSlotInts = (size_t)96 << 10;
+// holds the backward row of all column tiles + two boundary columns: windows up to ~16 kb), then 16 Mi
+// ints of H rows for the generic kernel.  448 MiB of the 288 GB, allocated once per context.
+constexpr int kLongBlocks = 512, kLongWaves = kLongBlocks * 4;   // 2 waves per SIMD
+constexpr size_t kLongSlotInts = (size_t)48 << 10;
 constexpr size_t kScratchInts = kLongWaves * kLongSlotInts + ((size_t)16 << 20);
 // device layout of the `counters` buffer: int32[kCntTotal] | pad | u64 cells | u64 scratch_used
 constexpr size_t kCellsOff = 64 * sizeof(int32_t);
@@ -366,7 +366,7 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     }
     if (!out_cn || !out_score || !out_n || !out_start) return fail(STRK_E_INVALID, "output pointer is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    const int ts = 2 * p.window + 1;
+    const int ts = std::min(kTableMax - 1, 2 * (p.window + 7) + 1);   // room for k_plan's per-read widening
     if ((rc = ensure_workspace(c, b->n_reads, b->n_loci, (size_t)b->n_reads * ts, (size_t)b->n_reads))) return rc;
     KArgs a = make_args(c, b, p.end_flags, p.window, ts, b->n_reads, &p);
     ReplayArgs rp;

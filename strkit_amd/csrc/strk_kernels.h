@@ -200,7 +200,10 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
             n = 0;
         } else if (mode == 0) {
             const long long est = a.est_cn[r];
-            long long w_lo = est - a.window, w_hi = est + a.window;
+            // the estimate round(|tr| / |motif|) drifts with the copy number (indels accumulate): widen the
+            // window by one size per 128 copies, as far as the table stride allows
+            const long long w = min((long long)a.window + min(max(est, 0ll) >> 7, 7ll), (long long)(a.table_stride - 1) / 2);
+            long long w_lo = est - w, w_hi = est + w;
             if (w_lo < 0) w_lo = 0;
             if (w_hi < w_lo) w_hi = w_lo;  // negative estimates: keep a one-entry window at 0
             if (w_hi - w_lo + 1 > a.table_stride) w_hi = w_lo + a.table_stride - 1;
@@ -1014,11 +1017,22 @@ __global__ void __launch_bounds__(256) k_dp_long(KArgs a) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 int edgePrev = from_left<G>(inner ? cIn[0] : 0, hout, first);
                 int gr = -g * lane;
-                int rowi = -lane;                              // 0-based row this lane works on at step 0
-                int ph = 0;                                    // (rowi - nfl) mod m once rowi >= nfl
                 int lastmax = kNegInf;
                 int forkG = g * (nfl + lo * m);
                 int forkIdx = 0;
+                // row symbols are generated two steps ahead (fl from LDS, then the motif with a running
+                // phase), the row word one step ahead, so both LDS latencies hide behind a DP row
+                int rowi = -lane;                              // 0-based row of the symbol generated next
+                int ph = 0;                                    // (rowi - nfl) mod m once rowi >= nfl
+                auto next_sym = [&]() -> int {
+                    int sym = kNullSym;
+                    if (rowi >= 0) sym = rowi < nfl ? flL[rowi] : motifL[ph];
+                    if (rowi >= nfl) { ++ph; if (ph == m) ph = 0; }
+                    ++rowi;
+                    return sym;
+                };
+                uint2 wordNext = tbl[next_sym()];
+                int symNext = next_sym();
                 for (int t0 = 0; t0 < stepsF; t0 += 64) {
                     int edgeIn = 0;
                     if (inner) edgeIn = cIn[t0 + 1 + lane];    // rows t0+1 .. t0+64 of the left neighbour slot
@@ -1026,11 +1040,9 @@ __global__ void __launch_bounds__(256) k_dp_long(KArgs a) {
 #define STRK_LF(SRC, DST, U)                                                                        \
                     {                                                                               \
                         const int t = t0 + (U);                                                     \
-                        int sym = kNullSym;                                                         \
-                        if (rowi >= 0) sym = rowi < nfl ? flL[rowi] : motifL[ph];                   \
-                        if (rowi >= nfl) { ++ph; if (ph == m) ph = 0; }                             \
-                        ++rowi;                                                                     \
-                        const uint2 word = tbl[sym];                                                \
+                        const uint2 word = wordNext;                                                \
+                        wordNext = tbl[symNext];                                                    \
+                        symNext = next_sym();                                                       \
                         const int keep = inner ? __builtin_amdgcn_readlane(edgeIn, (U)) : bstep * (t + 1); \
                         const int edge = from_left<G>(keep, hout, first);                           \
                         hout = dp_row<NQ, true>(SRC, DST, sel, word, edge, edgePrev);               \
