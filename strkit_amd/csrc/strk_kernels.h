@@ -12,7 +12,7 @@
 //     one backward DP over the fr rows give every S[i] as max_j(Gf(R_i,j) + Gb(j)) - const at the
 //     "fork rows" R_i = |fl| + i*|motif| (exact because gaps are linear, so DP nodes carry no
 //     affine state).  ~8x fewer cell updates than one DP per candidate.
-//   * A read is owned by a group of G lanes (16, 32 or 64); each lane keeps CL consecutive db columns
+//   * A read is owned by a group of G lanes (8, 16, 32 or 64); each lane keeps CL consecutive db columns
 //     of the DP row in VGPRs and the group runs a skewed (anti-diagonal) systolic wavefront: lane
 //     l works on row t-l at step t and hands its last column to lane l+1 with one DPP row/wave
 //     shift.  Substitution scores come from one v_perm_b32 per 4 cells on an 8-byte per-row word
@@ -29,23 +29,29 @@ namespace strk {
 
 constexpr int kTableMax = 32;       // max candidates per read in one DP item
 constexpr int kNegInf = -(1 << 29);
+constexpr int kFastFlankMax = 127;  // right-flank rows the fast classes stage in LDS (the default flank is 70)
 constexpr int kMotifMax = 256;     // the fast kernel stages the encoded motif in LDS (<= 2 * smallest capacity bytes)
 constexpr int kRowSlack = 160;      // a class of capacity CAP accepts up to CAP + kRowSlack prefix rows
 
 // Fast-kernel classes: (G lanes per read, CL columns per lane); capacity = G*CL slots >= |db| + 1.
-//   classes 0-5  : G = 16, CL = 8..28   (capacity 128..448,  4 reads per wave)
-//   classes 6-9  : G = 32, CL = 16..28  (capacity 512..896,  2 reads per wave)
-//   classes 10-13: G = 64, CL = 16..28  (capacity 1024..1792, 1 read per wave)
-constexpr int kNumClasses = 14;
+//   classes 0-6  : G = 8,  CL = 16..40  (capacity 128..320,   8 reads per wave)
+//   classes 7-8  : G = 16, CL = 24, 28  (capacity 384, 448,   4 reads per wave)
+//   classes 9-12 : G = 32, CL = 16..28  (capacity 512..896,   2 reads per wave)
+//   classes 13-16: G = 64, CL = 16..28  (capacity 1024..1792, 1 read per wave)
+// Fewer lanes per read = fewer skew steps and less per-step overhead per cell; the VGPR budget
+// (two CL-sized row arrays) and the per-read LDS footprint cap CL at 40.
+constexpr int kNumClasses = 17;
+__host__ __device__ constexpr int class_G(int c) { return c < 7 ? 8 : (c < 9 ? 16 : (c < 13 ? 32 : 64)); }
+__host__ __device__ constexpr int class_CL(int c) {
+    return c < 7 ? 16 + 4 * c : (c < 9 ? 24 + 4 * (c - 7) : (c < 13 ? 16 + 4 * (c - 9) : 16 + 4 * (c - 13)));
+}
+__host__ __device__ constexpr int class_cap(int c) { return class_G(c) * class_CL(c); }
 constexpr int kLongClass = kNumClasses;         // list of the column-tiled long-read kernel (k_dp_long)
 constexpr int kGenericClass = kNumClasses + 1;  // list of the generic kernel
 constexpr int kNumLists = kNumClasses + 2;
 constexpr int kLongTile = 64 * 28;              // slots per column tile of k_dp_long (G = 64, CL = 28)
 constexpr int kLongMaxTiles = 64;               // |db| + 1 <= 114 688
 constexpr int kLongFlankMax = 255;              // k_dp_long keeps both flanks' row symbols in LDS
-__host__ __device__ constexpr int class_G(int c) { return c < 6 ? 16 : (c < 10 ? 32 : 64); }
-__host__ __device__ constexpr int class_CL(int c) { return c < 6 ? 8 + 4 * c : (c < 10 ? 16 + 4 * (c - 6) : 16 + 4 * (c - 10)); }
-__host__ __device__ constexpr int class_cap(int c) { return class_G(c) * class_CL(c); }
 
 __constant__ int8_t c_mat[kNSym][kNSym];
 __constant__ uint8_t c_enc[256];
@@ -112,7 +118,7 @@ __device__ inline int classify(int nfl, int ntr, int nfr, int m, int lo, int n, 
     if (force_generic || nfl < 1 || (nfr < 1 && !ref_mode) || n > kTableMax || m > kMotifMax) return kGenericClass;
     for (int c = ref_mode ? kNumClasses - 1 : 0; c < kNumClasses; ++c) {  // ref mode: one specialisation (the widest class)
         const int cap = class_cap(c);
-        if (ndb + 1 <= cap && rows <= cap + kRowSlack) return c;
+        if (ndb + 1 <= cap && rows <= cap + kRowSlack && (nfr <= kFastFlankMax || ref_mode)) return c;
     }
     if (!ref_mode && nfl <= kLongFlankMax && nfr <= kLongFlankMax && ndb + 1 <= (long long)kLongTile * kLongMaxTiles &&
         rows <= (1 << 20))
@@ -267,25 +273,25 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
 // Fast DP kernel
 // ---------------------------------------------------------------------------------------------
 constexpr int kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;  // gfx9 DPP controls, present on gfx950
-constexpr int kCLMax = 28;   // columns per lane of the largest class
+constexpr int kCLMax = 40;   // columns per lane of the largest class
 constexpr int kNQMax = kCLMax / 4;
 
 constexpr int kDppRowShr1 = 0x111, kDppRowShl1 = 0x101;
 // from_left<G>(keep, v): lane l gets v of lane l-1; the first lane of every group gets `keep`.
 //   G = 16: a DPP row is one group (row_shr:1 leaves `keep` in its first lane);
-//   G = 64: wave_shr:1;  G = 32: wave_shr:1, then a select patches the seam lane (32 / 31).
+//   G = 64: wave_shr:1;  G = 32 / 8: wave_shr:1 / row_shr:1, then a select patches the seam lanes.
 // `keep` must be wave-uniform (it is the boundary value of the group's edge lane at this step).
 template <int G>
 __device__ __forceinline__ int from_left(int keep, int v, bool edge_lane) {
     if (G == 16) return __builtin_amdgcn_update_dpp(keep, v, kDppRowShr1, 0xf, 0xf, false);
-    const int x = __builtin_amdgcn_update_dpp(keep, v, kDppWaveShr1, 0xf, 0xf, false);
-    return (G == 32 && edge_lane) ? keep : x;
+    const int x = __builtin_amdgcn_update_dpp(keep, v, G == 8 ? kDppRowShr1 : kDppWaveShr1, 0xf, 0xf, false);
+    return ((G == 32 || G == 8) && edge_lane) ? keep : x;
 }
 template <int G>
 __device__ __forceinline__ int from_right(int keep, int v, bool edge_lane) {
     if (G == 16) return __builtin_amdgcn_update_dpp(keep, v, kDppRowShl1, 0xf, 0xf, false);
-    const int x = __builtin_amdgcn_update_dpp(keep, v, kDppWaveShl1, 0xf, 0xf, false);
-    return (G == 32 && edge_lane) ? keep : x;
+    const int x = __builtin_amdgcn_update_dpp(keep, v, G == 8 ? kDppRowShl1 : kDppWaveShl1, 0xf, 0xf, false);
+    return ((G == 32 || G == 8) && edge_lane) ? keep : x;
 }
 
 // LDS operations of one group never leave its wave: order them with a wave-level fence.
@@ -295,10 +301,12 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// max over the (at most four) groups of a wave of a value that is uniform inside each group
+// max over the (at most eight) groups of a wave of a value that is uniform inside each group
 __device__ __forceinline__ int wave_max_over_groups(int v) {
-    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    int m = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+    for (int l = 8; l < 64; l += 8) m = max(m, __builtin_amdgcn_readlane(v, l));
+    return m;
 }
 
 // Per-group LDS layout of a class (G lanes x CL columns); all offsets are multiples of 16.
@@ -313,7 +321,7 @@ struct DpLayout {
           off_db(OFF_MISC + 16),                                             // 4 pad + CAP + 4 pad bytes
           off_cp(off_db + ((G * CL + 8 + 15) & ~15)),                        // prefix rows
           off_ct(off_cp + ((G * CL + kRowSlack + 2 * G + 4 + 15) & ~15)),    // tail rows (reversed fr)
-          off_b0(off_ct + ((G * CL + 2 * G + 4 + 15) & ~15)),                // backward result, u16 per slot
+          off_b0(off_ct + ((kFastFlankMax + 2 * G + 4 + 15) & ~15)),         // backward result, u16 per slot
           group_bytes(off_b0 + ((G * CL * 2 + 15) & ~15)) {}
 };
 __host__ __device__ constexpr int wave_lds_bytes(int c) { return (64 / class_G(c)) * DpLayout(class_G(c), class_CL(c)).group_bytes; }
@@ -699,19 +707,22 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
         fwd_pass_ref<7, 64>(x, rowsP, cp, nEff, fork0, m, reinterpret_cast<unsigned long long*>(comb));
     } else
     switch (cls) {
-    case 0: STRK_PASSES(2, 16) break;
-    case 1: STRK_PASSES(3, 16) break;
-    case 2: STRK_PASSES(4, 16) break;
-    case 3: STRK_PASSES(5, 16) break;
-    case 4: STRK_PASSES(6, 16) break;
-    case 5: STRK_PASSES(7, 16) break;
-    case 6: STRK_PASSES(4, 32) break;
-    case 7: STRK_PASSES(5, 32) break;
-    case 8: STRK_PASSES(6, 32) break;
-    case 9: STRK_PASSES(7, 32) break;
-    case 10: STRK_PASSES(4, 64) break;
-    case 11: STRK_PASSES(5, 64) break;
-    case 12: STRK_PASSES(6, 64) break;
+    case 0: STRK_PASSES(4, 8) break;
+    case 1: STRK_PASSES(5, 8) break;
+    case 2: STRK_PASSES(6, 8) break;
+    case 3: STRK_PASSES(7, 8) break;
+    case 4: STRK_PASSES(8, 8) break;
+    case 5: STRK_PASSES(9, 8) break;
+    case 6: STRK_PASSES(10, 8) break;
+    case 7: STRK_PASSES(6, 16) break;
+    case 8: STRK_PASSES(7, 16) break;
+    case 9: STRK_PASSES(4, 32) break;
+    case 10: STRK_PASSES(5, 32) break;
+    case 11: STRK_PASSES(6, 32) break;
+    case 12: STRK_PASSES(7, 32) break;
+    case 13: STRK_PASSES(4, 64) break;
+    case 14: STRK_PASSES(5, 64) break;
+    case 15: STRK_PASSES(6, 64) break;
     default: STRK_PASSES(7, 64) break;
     }
 #undef STRK_PASSES
@@ -750,8 +761,9 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     }
     wave_lds_sync();
 }
-static_assert(kCLMax == 28 && kNumClasses == 14 && class_CL(0) == 8 && class_CL(6) == 16 && class_CL(10) == 16,
-              "dp_wave dispatches the 14 (CL/4, G) classes by index");
+static_assert(kNumClasses == 17 && class_CL(0) == 16 && class_CL(6) == kCLMax && class_CL(7) == 24 && class_CL(9) == 16 &&
+                  class_CL(13) == 16 && class_G(16) == 64 && class_CL(16) == 28,
+              "dp_wave dispatches the 17 (CL/4, G) classes by index");
 
 template <bool REF>
 __device__ __forceinline__ void dp_kernel_body() {
@@ -798,7 +810,7 @@ __global__ void __launch_bounds__(256) k_dp_ref(KArgs a_by_value) {
     (void)a_by_value;
     dp_kernel_body<true>();
 }
-static_assert(class_CL(kNumClasses - 1) <= kCLMax && class_CL(5) <= kCLMax && class_CL(9) <= kCLMax, "kCLMax covers every class");
+static_assert(class_G(kNumClasses - 1) == 64 && class_CL(kNumClasses - 1) == 28, "k_dp_ref / k_dp_long use the widest class");
 
 // ---------------------------------------------------------------------------------------------
 // Long-read kernel: the same shared-prefix systolic DP for windows wider than the largest fast class
