@@ -5,6 +5,7 @@ gfx950 code objects without a GPU present, so this runs in the build container a
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -26,12 +27,23 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm); strkit_amd has no CPU fallback")
 
 
+STAMP_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash() -> str:
+    """Content hash of everything the library is built from (file times do not survive a copy of the tree)."""
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for rel in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    with open(STAMP_PATH) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -45,6 +57,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
     os.replace(tmp, LIB_PATH)
+    with open(STAMP_PATH + ".tmp.%d" % os.getpid(), "w") as f:
+        f.write(source_hash() + "\n")
+    os.replace(STAMP_PATH + ".tmp.%d" % os.getpid(), STAMP_PATH)
     return LIB_PATH
 
 
