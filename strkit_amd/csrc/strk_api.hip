@@ -9,8 +9,10 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -26,6 +28,10 @@ extern "C" int strk_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8
 namespace {
 
 thread_local std::string g_err;
+
+// batched calls submitted and not yet finished, over all contexts of this process: a call that will share the
+// device with others takes half the CU slots, so that the tail of one call and the head of the next co-run
+std::atomic<int> g_calls_in_flight{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -182,13 +188,16 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     if (time_dp) (void)hipEventRecord(c->ev[1], st);
     if (!force_generic) {
         // persistent-style grid: every wave pulls chunks from the device-side queue until it is empty
-        const int blocks = std::max(1, std::min(256 * 4, (a.list_stride + 3) / 4));
+        constexpr int kBlocksPerCU = std::max(1, std::min(8, (160 * 1024) / (4 * kWaveLdsBytes + kLdsSlack + 1024)));
+        static const int tune = getenv("STRKIT_AMD_DP_BLOCKS") ? atoi(getenv("STRKIT_AMD_DP_BLOCKS")) : 0;   // tuning aid
+        const int share = g_calls_in_flight.load(std::memory_order_relaxed) > 1 ? 2 : 1;   // this call is counted already
+        const int blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBlocksPerCU / share, (a.list_stride + 3) / 4));
         if (a.ref_mode) hipLaunchKernelGGL(k_dp_ref, dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);
     }
+    if (time_dp) (void)hipEventRecord(c->ev[2], st);   // ev[1]..ev[2] brackets the dominant kernel alone
     if (!force_generic && !a.ref_mode) hipLaunchKernelGGL(k_dp_long, dim3(kLongBlocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dp_generic, dim3(256), dim3(256), 0, st, a);
-    if (time_dp) (void)hipEventRecord(c->ev[2], st);
 }
 
 int check_error_bits(int bits) {
@@ -362,6 +371,7 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     c->p_stream = st;
     if (b->n_reads == 0 || b->n_loci == 0) {
         c->pending = true;
+        g_calls_in_flight.fetch_add(1, std::memory_order_relaxed);
         return 0;
     }
     if (!out_cn || !out_score || !out_n || !out_start) return fail(STRK_E_INVALID, "output pointer is NULL");
@@ -378,6 +388,11 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     rp.need_hi = rp.need_lo + b->n_loci;
     rp.frac = c->state_f64.as<double>();
 
+    struct InFlight {   // counted before the launches (the grid size depends on it), un-counted on any early error return
+        bool keep = false;
+        InFlight() { g_calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
+        ~InFlight() { if (!keep) g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+    } in_flight;
     HIP_TRY(hipEventRecord(c->ev[0], st));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
     if (a.rhash) hipLaunchKernelGGL(k_hash, dim3((b->n_reads + 255) / 256), dim3(256), 0, st, a);
@@ -389,6 +404,7 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     c->p_args = a;
     c->p_replay = rp;
     c->pending = true;
+    in_flight.keep = true;
     return 0;
 }
 
@@ -397,6 +413,7 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
     if (stats) memset(stats, 0, sizeof *stats);
     if (!c->pending) return fail(STRK_E_INVALID, "nothing was submitted on this context");
     c->pending = false;
+    g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed);
     const strk_batch* b = &c->p_batch;
     if (b->n_reads == 0 || b->n_loci == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
