@@ -72,6 +72,10 @@ typedef struct strk_params {
     int32_t no_dedupe;          /* 0 (default): reads of a locus with identical bytes, split and estimate
                                    share one score table (the reference's lru_cache, repeats.py:47);
                                    1: score every read separately */
+    int32_t no_band;            /* 0 (default): reads whose window is much wider than the band the search can
+                                   reach are scored by the banded kernel first and re-scored exactly only when
+                                   the exactness certificate fails; 1: exact kernels only */
+    int32_t reserved;
 } strk_params;
 
 /* CSR-packed batch of loci.  Read r owns seqs[seq_off[r] .. seq_off[r+1]) laid out fl|tr|fr;
@@ -102,6 +106,8 @@ typedef struct strk_stats {
     float dp_kernel_ms;    /* ... of the DP kernels alone */
     int32_t n_dp_launches;
     int32_t n_dedup_reads; /* reads served by the score table of an identical earlier read */
+    int32_t n_band_reads;  /* reads scored by the banded kernel ... */
+    int32_t n_band_fallback; /* ... of which the certificate failed (re-scored by the exact kernels) */
 } strk_stats;
 
 int strk_init(int device, strk_ctx** out);

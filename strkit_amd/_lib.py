@@ -23,7 +23,7 @@ _i64p = C.POINTER(C.c_int64)
 class StrkParams(C.Structure):
     _fields_ = [("max_iters", C.c_int32), ("local_search_range", C.c_int32), ("step_size", C.c_int32),
                 ("tie_rule", C.c_int32), ("end_flags", C.c_int32), ("feedback", C.c_int32), ("window", C.c_int32),
-                ("no_dedupe", C.c_int32)]
+                ("no_dedupe", C.c_int32), ("no_band", C.c_int32), ("reserved", C.c_int32)]
 
 
 class StrkBatch(C.Structure):
@@ -35,7 +35,8 @@ class StrkBatch(C.Structure):
 class StrkStats(C.Structure):
     _fields_ = [("dp_cells", C.c_int64), ("n_fallback", C.c_int32), ("n_miss_reads", C.c_int32),
                 ("n_miss_rounds", C.c_int32), ("kernel_ms", C.c_float), ("dp_kernel_ms", C.c_float),
-                ("n_dp_launches", C.c_int32), ("n_dedup_reads", C.c_int32)]
+                ("n_dp_launches", C.c_int32), ("n_dedup_reads", C.c_int32), ("n_band_reads", C.c_int32),
+                ("n_band_fallback", C.c_int32)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -19,13 +19,13 @@ __all__ = ["count_loci", "score_table", "score_ref_table", "make_params", "batch
 
 def make_params(rc_params: RepeatCountParams | None = None, feedback: bool = True, window: int = 0,
                 tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL,
-                dedupe: bool = True) -> _lib.StrkParams:
+                dedupe: bool = True, band: bool = True) -> _lib.StrkParams:
     rc = rc_params or default_read_rc_params()
     if rc.method != "repalign":
         raise NotImplementedError("only rc_method='repalign' runs on the GPU backend")
     return _lib.StrkParams(max_iters=rc.max_iters, local_search_range=rc.initial_local_search_range,
                            step_size=rc.initial_step_size, tie_rule=tie_rule, end_flags=end_flags,
-                           feedback=int(feedback), window=window, no_dedupe=int(not dedupe))
+                           feedback=int(feedback), window=window, no_dedupe=int(not dedupe), no_band=int(not band), reserved=0)
 
 
 def _ptr(a: np.ndarray) -> int:
@@ -47,10 +47,10 @@ def batch_struct(b: LocusBatch):
 
 def count_loci(b: LocusBatch, rc_params: RepeatCountParams | None = None, feedback: bool = True, window: int = 0,
                tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL, ctx: _lib.Context | None = None,
-               with_stats: bool = False, dedupe: bool = True):
+               with_stats: bool = False, dedupe: bool = True, band: bool = True):
     """Per-read (cn, score, n_iters, start) for every read of the batch, as int32 arrays."""
     ctx = ctx or _lib.default_context()
-    p = make_params(rc_params, feedback, window, tie_rule, end_flags, dedupe)
+    p = make_params(rc_params, feedback, window, tie_rule, end_flags, dedupe, band)
     s, keep = batch_struct(b)
     n = max(b.n_reads, 1)
     out = {k: np.zeros(n, np.int32) for k in ("cn", "score", "n_iters", "start")}

@@ -80,7 +80,7 @@ struct DevBuf {
 struct strk_ctx {
     int device = 0;
     // workspace
-    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, counters, scratch, state_i32, state_f64, spec, rhash, rep;
+    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, counters, scratch, state_i32, state_f64, spec, rhash, rep, exact;
     DevBuf win_lo2, win_n2, tab_off2, table2, items;
     // staging for the host-buffer entry points
     DevBuf in_seqs, in_seq_off, in_nfl, in_ntr, in_nfr, in_est, in_read_off, in_motifs, in_motif_off;
@@ -88,6 +88,7 @@ struct strk_ctx {
     int32_t* h_counters = nullptr;  // pinned: counters + cells + scratch_used
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_ints = 0;
+    int band_cooldown = 0;   // > 0: the band kernel is switched off for that many calls (too many certificates failed)
     // one submitted-but-not-finished batched call (strk_submit_loci_device .. strk_finish)
     bool pending = false;
     strk_batch p_batch;
@@ -105,6 +106,7 @@ constexpr int kDefaultWindow = 8;
 // Scratch pool (int32 units): kLongWaves slots of kLongSlotInts for k_dp_long (one per resident wave; a slot
 // holds the backward row of all column tiles + two boundary columns: windows up to ~16 kb), then 16 Mi
 // ints of H rows for the generic kernel.  448 MiB of the 288 GB, allocated once per context.
+constexpr int kBandBlocksPerCU = std::max(1, std::min(8, (160 * 1024) / (4 * kBandWaveLds + kLdsSlack + 1024)));
 constexpr int kLongBlocks = 512, kLongWaves = kLongBlocks * 4;   // 2 waves per SIMD
 constexpr size_t kLongSlotInts = (size_t)48 << 10;
 constexpr size_t kScratchInts = kLongWaves * kLongSlotInts + ((size_t)16 << 20);
@@ -140,6 +142,7 @@ int ensure_workspace(strk_ctx* c, int n_reads, int n_loci, size_t table_ints, si
     if ((rc = c->spec.ensure(nr * 16))) return rc;
     if ((rc = c->rhash.ensure(nr * 8))) return rc;
     if ((rc = c->rep.ensure(nr * 4))) return rc;
+    if ((rc = c->exact.ensure(nr))) return rc;
     if (!c->scratch.p) {
         if ((rc = c->scratch.ensure(kScratchInts * 4))) return rc;
         c->scratch_ints = kScratchInts;
@@ -177,6 +180,8 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
         a.tie_last = sp->tie_rule == STRK_TIE_LAST;
         a.rep = c->rep.as<int32_t>();
         a.rhash = sp->no_dedupe ? nullptr : c->rhash.as<unsigned long long>();
+        a.exact = c->exact.as<uint8_t>();
+        a.band_mode = (!sp->no_band && c->band_cooldown == 0) ? 1 : 0;
     }
     return a;
 }
@@ -185,6 +190,10 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
 void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_items, int n_items, int force_generic,
                      hipStream_t st, bool time_dp) {
     hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, a, mode, d_items, n_items, force_generic);
+    if (a.band_mode && mode == 0 && !force_generic) {
+        // banded first pass: certified reads are done, the others are appended to the exact lists below
+        hipLaunchKernelGGL(k_dp_band, dim3(256 * kBandBlocksPerCU), dim3(256), 0, st, a);
+    }
     if (time_dp) (void)hipEventRecord(c->ev[1], st);
     if (!force_generic) {
         // persistent-style grid: every wave pulls chunks from the device-side queue until it is empty
@@ -239,6 +248,18 @@ int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs
     HIP_TRY(hipMemcpy(o_n.data(), rp.out_n, (size_t)nr * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(o_start.data(), rp.out_start, (size_t)nr * 4, hipMemcpyDeviceToHost));
 
+    // banded tables (lower bounds + certificate) need the read geometry on the host as well
+    std::vector<uint8_t> exact_h;
+    std::vector<int32_t> rep_h, nfl_h, ntr_h, nfr_h, motif_off_h;
+    if (a.band_mode) {
+        exact_h.resize(nr); rep_h.resize(nr); nfl_h.resize(nr); ntr_h.resize(nr); nfr_h.resize(nr); motif_off_h.resize(nl + 1);
+        HIP_TRY(hipMemcpy(exact_h.data(), a.exact, (size_t)nr, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(rep_h.data(), a.rep, (size_t)nr * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(nfl_h.data(), b->nfl, (size_t)nr * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ntr_h.data(), b->ntr, (size_t)nr * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(nfr_h.data(), b->nfr, (size_t)nr * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(motif_off_h.data(), b->motif_off, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost));
+    }
     std::vector<int> pending;  // loci
     for (int l = 0; l < nl; ++l)
         if (next_read[l] < read_off[l + 1]) pending.push_back(l);
@@ -288,6 +309,8 @@ int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs
         a2.cls_list = c->cls_list.as<int32_t>();
         a2.list_stride = (int32_t)n_chunks;
         a2.spec = nullptr;
+        a2.band_mode = 0;   // window-miss rounds always score exactly
+        a2.exact = nullptr;
         HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
         enqueue_scoring(c, a2, 1, c->items.as<int32_t>(), (int)items.size(), 0, st, false);
         HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
@@ -320,8 +343,20 @@ int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs
                 const int32_t n = use_ext ? (int32_t)ext[r].size() : win_n[r];
                 SeenVec seen;
                 seen.v.assign((size_t)std::max(n, 1), 0);
-                const SearchResult res = search_replay(start, p.step_size, p.local_search_range, p.max_iters,
-                                                       p.tie_rule == STRK_TIE_LAST, sc, lo, n, seen);
+                SearchResult res;
+                if (use_ext || !a.band_mode || exact_h[(size_t)rep_h[r]]) {
+                    res = search_replay(start, p.step_size, p.local_search_range, p.max_iters, p.tie_rule == STRK_TIE_LAST, sc,
+                                        lo, n, seen);
+                } else {   // banded table of the device pass: same certified search as k_replay
+                    const int rp = rep_h[r];
+                    const int m = motif_off_h[l + 1] - motif_off_h[l];
+                    const BandGeo geo = band_geometry(nfl_h[rp], ntr_h[rp], nfr_h[rp], m, lo, n);
+                    auto ub = [&](int k) { return band_ub(geo, nfl_h[rp], ntr_h[rp], nfr_h[rp], m, lo + k, p.end_flags); };
+                    const CertResult cr = search_replay_cert(start, p.step_size, p.local_search_range, p.max_iters,
+                                                             p.tie_rule == STRK_TIE_LAST, sc, lo, n, seen, ub);
+                    res = cr.res;
+                    if (cr.uncertain) { res.miss = 1; res.need_lo = lo; res.need_hi = lo + n - 1; }
+                }
                 if (res.miss) {
                     need_lo[l] = res.need_lo;
                     need_hi[l] = res.need_hi;
@@ -426,7 +461,14 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         stats->n_dp_launches = 2;
         stats->n_fallback = c->h_counters[kCntClass0 + kGenericClass];
         stats->n_dedup_reads = c->h_counters[kCntDup];
+        stats->n_band_reads = c->h_counters[kCntClass0 + kBandClass0] + c->h_counters[kCntClass0 + kBandClass0 + 1];
+        stats->n_band_fallback = c->h_counters[kCntBandFallback];
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
+    }
+    {   // adaptive: noisy reads mostly fail the certificate and pay for both passes
+        const int nb = c->h_counters[kCntClass0 + kBandClass0] + c->h_counters[kCntClass0 + kBandClass0 + 1];
+        if (c->band_cooldown > 0) --c->band_cooldown;
+        else if (nb >= 64 && 2 * c->h_counters[kCntBandFallback] > nb) c->band_cooldown = 32;
     }
     const int err = c->h_counters[kCntError];
     int rc;
@@ -732,7 +774,7 @@ void strk_destroy(strk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->read_locus, &c->win_lo, &c->win_n, &c->tab_off, &c->table, &c->cls_list, &c->counters,
-                      &c->scratch, &c->state_i32, &c->state_f64, &c->spec, &c->rhash, &c->rep, &c->win_lo2, &c->win_n2, &c->tab_off2, &c->table2,
+                      &c->scratch, &c->state_i32, &c->state_f64, &c->spec, &c->rhash, &c->rep, &c->exact, &c->win_lo2, &c->win_n2, &c->tab_off2, &c->table2,
                       &c->items, &c->in_seqs, &c->in_seq_off, &c->in_nfl, &c->in_ntr, &c->in_nfr, &c->in_est,
                       &c->in_read_off, &c->in_motifs, &c->in_motif_off, &c->out_cn, &c->out_score, &c->out_n,
                       &c->out_start};

@@ -48,7 +48,8 @@ __host__ __device__ constexpr int class_CL(int c) {
 __host__ __device__ constexpr int class_cap(int c) { return class_G(c) * class_CL(c); }
 constexpr int kLongClass = kNumClasses;         // list of the column-tiled long-read kernel (k_dp_long)
 constexpr int kGenericClass = kNumClasses + 1;  // list of the generic kernel
-constexpr int kNumLists = kNumClasses + 2;
+constexpr int kBandClass0 = kNumClasses + 2;    // band kernel lists: +0 -> G = 8 (128 diagonals), +1 -> G = 16 (256)
+constexpr int kNumLists = kNumClasses + 4;
 constexpr int kLongTile = 64 * 28;              // slots per column tile of k_dp_long (G = 64, CL = 28)
 constexpr int kLongMaxTiles = 64;               // |db| + 1 <= 114 688
 constexpr int kLongFlankMax = 255;              // k_dp_long keeps both flanks' row symbols in LDS
@@ -91,6 +92,8 @@ struct KArgs {
     int32_t window;       // half width (plan kernel)
     int32_t table_stride; // entries per read (plan kernel)
     int32_t max_iters, lsr, step, tie_last;  // search parameters (speculative search in k_dp_all)
+    int32_t band_mode;    // 1: eligible reads go through k_dp_band first (strk_search.h, "Banded scoring")
+    uint8_t* exact;       // [n_reads] 1: the read's table holds exact scores, 0: band lower bounds
     int32_t ref_mode;     // 1: reference-side scoring (repeats.py:23-43): candidate = fl + motif*i only, the
                           //    table holds (score, end_query) pairs, end_flags must be STRK_DB_END_FREE
 };
@@ -102,7 +105,9 @@ enum Counter {
     kCntNextChunk = kNumLists + 2,        // work queue head of k_dp_all
     kCntDup = kNumLists + 3,              // reads that share the score table of an identical earlier read
     kCntNextLong = kNumLists + 4,         // work queue head of k_dp_long
-    kCntTotal = kNumLists + 5
+    kCntNextBand = kNumLists + 5,         // work queue head of k_dp_band
+    kCntBandFallback = kNumLists + 6,     // band reads whose search could not be certified (re-scored exactly)
+    kCntTotal = kNumLists + 7
 };
 constexpr int kErrBadInput = 1;   // empty motif / negative length
 constexpr int kErrScratch = 2;    // generic scratch exhausted
@@ -237,12 +242,20 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     // Long windows (window-miss rounds, explicit tables) are cut into items of <= kTableMax sizes.
     unsigned long long cells = 0;
     const unsigned long long ndb = (unsigned long long)nfl + ntr + nfr;
+    int band_list = -1;   // >= 0: the read goes to the band kernel first
+    if (a.band_mode && mode == 0 && n > 0 && n <= kTableMax && !force_generic) {
+        const BandGeo geo = band_geometry(nfl, ntr, nfr, m, lo, n);
+        if (geo.ok) band_list = kBandClass0 + (geo.G == 16 ? 1 : 0);
+    }
+    if (a.exact && gid < n_items && n > 0) a.exact[r] = band_list < 0;
     for (int k0 = 0; k0 < n; k0 += kTableMax) {
         const int nn = min(kTableMax, n - k0);
-        const int c = classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic, a.ref_mode);
+        const int c = band_list >= 0 ? band_list : classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic, a.ref_mode);
         atomicAdd(&s_cnt[c], 1);
         if (c == kGenericClass) {
             for (int k = 0; k < nn; ++k) cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + k) * m + nfr);
+        } else if (band_list >= 0) {
+            cells += (unsigned long long)(band_list == kBandClass0 ? 128 : 256) * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
         } else {
             cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
         }
@@ -258,7 +271,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     __syncthreads();
     for (int k0 = 0; k0 < n; k0 += kTableMax) {
         const int nn = min(kTableMax, n - k0);
-        const int c = classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic, a.ref_mode);
+        const int c = band_list >= 0 ? band_list : classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic, a.ref_mode);
         const int idx = s_base[c] + atomicAdd(&s_cnt[c], 1);
         if (idx < a.list_stride) {
             a.cls_list[(size_t)c * a.list_stride * 2 + 2 * idx] = r;
@@ -813,6 +826,336 @@ __global__ void __launch_bounds__(256) k_dp_ref(KArgs a_by_value) {
 static_assert(class_G(kNumClasses - 1) == 64 && class_CL(kNumClasses - 1) == 28, "k_dp_ref / k_dp_long use the widest class");
 
 // ---------------------------------------------------------------------------------------------
+// Band kernel (see strk_search.h "Banded scoring with an exactness certificate").  Lanes own
+// DIAGONALS instead of columns: lane l of a group keeps the 16 diagonals d = dlo + 16 l .. + 15 of the
+// current row, so a group of 8 (16) lanes covers a band of 128 (256) diagonals that follows the
+// alignment down the matrix.  Per row and slot k:
+//     up   = (r-1, j)   = old[k+1]   (the next lane's old[0] for k = 15: a second DPP, mid-step)
+//     left = (r, j-1)   = new[k-1]   (the previous lane's new[15] for k = 0: the systolic skew)
+//     diag = (r-1, j-1) = old[k] + w
+// and the selector bytes of the lane's 16 columns slide by one column per row (four v_alignbyte plus
+// one LDS byte).  Cells outside the band are 0 in G-space (= -inf: every real value is >= 0), cells
+// left of column 1 carry the left-boundary value, cells right of the last column replicate it.
+// The backward pass is the same function on the reversed right flank and the reversed window.
+// ---------------------------------------------------------------------------------------------
+struct BandLayout {
+    int wd, pad, maxdb, off_sel, off_cp, off_ct, off_b0, group_bytes, sel_len;
+    static constexpr int OFF_TBL = 0, OFF_COMB = 18 * 8, OFF_MISC = OFF_COMB + kTableMax * 4;
+    __host__ __device__ constexpr BandLayout(int G)
+        : wd(16 * G), pad(16 * G + G + 8), maxdb(G == 8 ? kBandMaxDb8 : kBandMaxDb16),
+          off_sel(OFF_MISC + 16),
+          off_cp(off_sel + ((maxdb + 2 * (16 * G + G + 8) + 15) & ~15)),
+          off_ct(off_cp + ((maxdb + kBandRowSlack + 2 * G + 4 + 15) & ~15)),
+          off_b0(off_ct + ((kBandMaxFlank + 2 * G + 4 + 15) & ~15)),
+          group_bytes(off_b0 + (((G == 8 ? kBandMaxCol8 : kBandMaxCol16) * 2 + 15) & ~15)),
+          sel_len(maxdb + 2 * (16 * G + G + 8)) {}
+};
+constexpr int kBandWaveLds = (8 * BandLayout(8).group_bytes > 4 * BandLayout(16).group_bytes) ? 8 * BandLayout(8).group_bytes
+                                                                                             : 4 * BandLayout(16).group_bytes;
+constexpr int kBandNeg16 = -20000;
+
+struct BandCtx {
+    int lig;
+    bool first, last;
+    const uint2* tbl;
+    const uint8_t* selb;   // class-byte array: selb[pad + x] <-> db[x], 0x0c elsewhere
+    int pad, maxidx, ndb;
+};
+
+// One banded pass over `nrows` rows.  BWD = false: forward pass (columns = db, left to right);
+// BWD = true: backward pass in reversed coordinates (columns = reversed db).  dlo_ is the first
+// diagonal of the band, topFree/leftFree the free-end flags of the top row / left column.
+template <int G, bool BWD>
+__device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsym, int nrows, int dlo_, bool topFree,
+                                          bool leftFree, int nEff, int fork0, int m, int cmin, int ncol, int* comb,
+                                          short* b0col) {
+    constexpr int g = kGap;
+    const int ncols = x.ndb;
+    const int d0 = dlo_ + x.lig * 16;                 // diagonal of this lane's slot 0
+    auto g0 = [&](int j) -> int { return topFree ? g * min(max(j, 0), ncols) : 0; };   // row-0 pattern
+    auto col_addr = [&](int j) -> int {               // LDS index of the class byte of column j (1-based)
+        const int idx = BWD ? x.pad + ncols - j : x.pad + j - 1;
+        return min(max(idx, 0), x.maxidx);
+    };
+    int Ha[16], Hb[16];
+    unsigned sel[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Ha[k] = g0(-x.lig + d0 + k);
+    {
+        const int j0 = 1 - x.lig + d0;                // column of slot 0 at the row of step 0
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v |= (unsigned)x.selb[col_addr(j0 + 4 * q + b)] << (8 * b);
+            sel[q] = v;
+        }
+    }
+    const int T = (wave_max_over_groups(nrows > 0 ? nrows + G - 1 : 0) + 1) & ~1;
+    const int dhi_ = dlo_ + 16 * G - 1;
+    int houtL = Ha[15];
+    int gr = -g * x.lig;                               // g * (row finished before step 0)
+    int jb = 1 - x.lig + d0;                           // column of slot 0 at the current step's row
+    int forkG = (!BWD && nEff > 0) ? g * fork0 : 0x7fffffff;
+    if (BWD) forkG = g * nrows;                        // the backward pass has one event: its last row
+    int forkIdx = 0;
+    const int gm = g * m;
+    const uint8_t* pa = rowsym + (G - 1) - x.lig;
+    uint2 wordNext = x.tbl[pa[0]];
+    unsigned symNext = pa[1];
+    unsigned nbNext = x.selb[col_addr(jb + 16)];       // class byte entering at the next row
+#define STRK_BAND_STEP(SRC, DST, TT)                                                               \
+    {                                                                                              \
+        const uint2 word = wordNext;                                                               \
+        wordNext = x.tbl[symNext];                                                                 \
+        symNext = pa[(TT) + 2];                                                                    \
+        const unsigned nb = nbNext;                                                                \
+        nbNext = x.selb[col_addr(jb + 17)];                                                        \
+        /* lane 0 works on row TT+1; left of the band lies the left boundary while j-1 <= 0 */      \
+        const int keepL = ((TT) + dlo_ <= 0 && leftFree) ? g * ((TT) + 1) : 0;                      \
+        const int leftEdge = from_left<G>(keepL, houtL, x.first);                                  \
+        /* the last lane works on row TT-G+2; above row 1 lies the row-0 pattern, else -inf */      \
+        const int rl = (TT) - G + 2;                                                               \
+        const int keepU = rl <= 1 ? g0(rl + dhi_) : 0;                                             \
+        const unsigned w0 = __builtin_amdgcn_perm(word.y, word.x, sel[0]);                         \
+        const unsigned w1 = __builtin_amdgcn_perm(word.y, word.x, sel[1]);                         \
+        const unsigned w2 = __builtin_amdgcn_perm(word.y, word.x, sel[2]);                         \
+        const unsigned w3 = __builtin_amdgcn_perm(word.y, word.x, sel[3]);                         \
+        DST[0] = max(max(SRC[1], leftEdge), SRC[0] + (int)(w0 & 0xffu));                           \
+        const int upEdge = from_right<G>(keepU, DST[0], x.last);                                   \
+        _Pragma("unroll") for (int k = 1; k < 15; ++k) {                                           \
+            const unsigned wq = k < 4 ? w0 : (k < 8 ? w1 : (k < 12 ? w2 : w3));                     \
+            DST[k] = max(max(SRC[k + 1], DST[k - 1]), SRC[k] + (int)((wq >> (8 * (k % 4))) & 0xffu)); \
+        }                                                                                          \
+        DST[15] = max(max(upEdge, DST[14]), SRC[15] + (int)(w3 >> 24));                            \
+        houtL = DST[15];                                                                           \
+        sel[0] = __builtin_amdgcn_alignbyte(sel[1], sel[0], 1);                                    \
+        sel[1] = __builtin_amdgcn_alignbyte(sel[2], sel[1], 1);                                    \
+        sel[2] = __builtin_amdgcn_alignbyte(sel[3], sel[2], 1);                                    \
+        sel[3] = __builtin_amdgcn_alignbyte(nb, sel[3], 1);                                        \
+        gr += g;                                                                                   \
+        if (gr == forkG) {                                                                         \
+            if (BWD) {                                                                             \
+                /* last row: slot k is reversed column jb + k, i.e. db node ndb - (jb + k) */       \
+                _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                   \
+                    const int jp = jb + k, idx = ncols - jp - cmin;                                \
+                    if (jp >= 0 && jp <= ncols && idx >= 0 && idx < ncol) b0col[idx] = (short)DST[k]; \
+                }                                                                                  \
+                forkG = 0x7fffffff;                                                                \
+            } else {                                                                               \
+                const short* bc = b0col + (jb - cmin);                                             \
+                int acc = kNegInf;                                                                 \
+                _Pragma("unroll") for (int k = 0; k < 16; k += 2)                                  \
+                    acc = max(max(acc, DST[k] + (int)bc[k]), DST[k + 1] + (int)bc[k + 1]);         \
+                atomicMax(&comb[forkIdx], acc);                                                    \
+                ++forkIdx;                                                                         \
+                forkG = forkIdx < nEff ? forkG + gm : 0x7fffffff;                                  \
+            }                                                                                      \
+        }                                                                                          \
+        ++jb;                                                                                      \
+    }
+    for (int t = 0; t < T; t += 2) {
+        STRK_BAND_STEP(Ha, Hb, t)
+        STRK_BAND_STEP(Hb, Ha, t + 1)
+    }
+#undef STRK_BAND_STEP
+}
+
+// Processes 64/G band items of list kBandClass0 + (G == 16), one per group.
+template <int G>
+__device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw, const uint8_t* s_enc, const int8_t* s_mat) {
+    constexpr int g = kGap;
+    constexpr BandLayout lay(G);
+    const int cls = kBandClass0 + (G == 16 ? 1 : 0);
+    const int lane = threadIdx.x & 63;
+    const int lig = lane & (G - 1);
+    const int grp = lane / G;
+    const bool first = lig == 0, last = lig == G - 1;
+    uint8_t* const Lg = Lw + grp * lay.group_bytes;
+    uint2* const tbl = reinterpret_cast<uint2*>(Lg + BandLayout::OFF_TBL);
+    int* const comb = reinterpret_cast<int*>(Lg + BandLayout::OFF_COMB);
+    int* const misc = reinterpret_cast<int*>(Lg + BandLayout::OFF_MISC);
+    uint8_t* const selb = Lg + lay.off_sel;
+    uint8_t* const cp = Lg + lay.off_cp;
+    uint8_t* const ct = Lg + lay.off_ct;
+    short* const b0col = reinterpret_cast<short*>(Lg + lay.off_b0);
+    uint8_t* const motifL = Lg + lay.off_b0;   // the motif sits there until the band columns are initialised
+
+    const int count = min(a.counters[kCntClass0 + cls], a.list_stride);
+    const int32_t* list = a.cls_list + (size_t)cls * a.list_stride * 2;
+    const int it = base + grp;
+    bool act = it < count;
+    int r = 0, nfl = 1, ntr = 0, nfr = 1, m = 1, lo = 0, n = 0;
+    long long soff = 0;
+    const uint8_t* motif = a.motifs;
+    if (act) {
+        r = list[2 * it];
+        nfl = a.nfl[r]; ntr = a.ntr[r]; nfr = a.nfr[r];
+        soff = a.seq_off[r];
+        const int l = a.read_locus[r];
+        motif += a.motif_off[l];
+        m = a.motif_off[l + 1] - a.motif_off[l];
+        lo = a.win_lo[r];
+        n = a.win_n[r];
+    }
+    const int ndb = nfl + ntr + nfr;
+    const BandGeo geo = band_geometry(nfl, ntr, nfr, m, lo, max(n, 1));
+    const int rowsP = act ? nfl + (lo + n - 1) * m : 0;
+    const int rowsT = act ? nfr : 0;
+    const bool dbBeg = a.end_flags & 1, dbEnd = a.end_flags & 2, cBeg = a.end_flags & 4, cEnd = a.end_flags & 8;
+
+    // ---- stage: class-byte array with pads, symbol set, row words, row symbols ------------------
+    if (first) misc[0] = 0;
+    wave_lds_sync();
+    {
+        unsigned mask = 0;
+        const uint8_t* seq = a.seqs + soff;
+        for (int s0 = lig; s0 < lay.sel_len; s0 += 4 * G) {
+            int raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = s0 + u * G - lay.pad;
+                raw[u] = (act && j >= 0 && j < ndb) ? (int)seq[j] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = s0 + u * G;
+                int sym = 0xff;
+                if (raw[u] >= 0) { sym = s_enc[raw[u]]; mask |= 1u << sym; }
+                if (s < lay.sel_len) selb[s] = (uint8_t)sym;
+            }
+        }
+        if (mask) atomicOr(reinterpret_cast<unsigned*>(&misc[0]), mask);
+        for (int k = lig; k < m; k += G) motifL[k] = act ? s_enc[motif[k]] : (uint8_t)kNullSym;
+    }
+    wave_lds_sync();
+    const unsigned symmask = (unsigned)misc[0];
+    bool fallback = act && __popc(symmask) > 8;   // more symbol classes than a v_perm word holds: exact path decides
+    for (int e = lig; e < 18; e += G) {
+        unsigned wlo = 0, whi = 0;
+        if (e < kNSym) {
+            int k = 0;
+            for (int s = 0; s < kNSym; ++s) {
+                if (!((symmask >> s) & 1u)) continue;
+                if (k < 8) {
+                    const unsigned b = (unsigned)(s_mat[e * kNSym + s] + kWBias) & 0xffu;
+                    if (k < 4) wlo |= b << (8 * k); else whi |= b << (8 * (k - 4));
+                }
+                ++k;
+            }
+        }
+        tbl[e] = make_uint2(wlo, whi);
+    }
+    for (int e = lig; e < kTableMax; e += G) comb[e] = kNegInf;
+    {
+        const int lenP = rowsP + 2 * (G - 1) + 4;
+        const int gstep = G % m;
+        int ph = (lig - (G - 1) - nfl) % m;
+        if (ph < 0) ph += m;
+        for (int idx = lig; idx < lenP; idx += G) {
+            const int row = idx - (G - 1);
+            int sym = kNullSym;
+            if (row >= 0 && row < rowsP) sym = row < nfl ? selb[lay.pad + row] : motifL[ph];
+            cp[idx] = (uint8_t)sym;
+            ph += gstep;
+            if (ph >= m) ph -= m;
+        }
+        const int lenT = rowsT + 2 * (G - 1) + 4;
+        for (int idx = lig; idx < lenT; idx += G) {
+            const int row = idx - (G - 1);
+            int sym = kNullSym;
+            if (row >= 0 && row < rowsT) sym = selb[lay.pad + ndb - 1 - row];
+            ct[idx] = (uint8_t)sym;
+        }
+    }
+    wave_lds_sync();
+    for (int wi = lig; wi < lay.sel_len / 4; wi += G) {   // symbols -> v_perm selector bytes
+        unsigned* const w = reinterpret_cast<unsigned*>(selb) + wi;
+        const unsigned v = *w;
+        unsigned o = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned sym = (v >> (8 * b)) & 0xffu;
+            o |= (sym < (unsigned)kNSym ? (unsigned)__popc(symmask & ((1u << sym) - 1u)) : 0x0cu) << (8 * b);
+        }
+        *w = o;
+    }
+    for (int k = lig; k < (G == 8 ? kBandMaxCol8 : kBandMaxCol16); k += G) b0col[k] = (short)kBandNeg16;
+    wave_lds_sync();
+
+    BandCtx x;
+    x.lig = lig; x.first = first; x.last = last; x.tbl = tbl; x.selb = selb;
+    x.pad = lay.pad; x.maxidx = lay.sel_len - 1; x.ndb = ndb;
+    const bool run = act && !fallback && geo.ok;
+    const int nEff = run ? n : 0;
+    // backward pass (reversed right flank x reversed window), then forward pass with the fork rows
+    band_pass<G, true>(x, ct, run ? rowsT : 0, geo.bdlo, dbEnd, cEnd, 0, 0, 1, geo.cmin, geo.ncol, comb, b0col);
+    wave_lds_sync();
+    band_pass<G, false>(x, cp, run ? rowsP : 0, geo.dlo, dbBeg, cBeg, nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col);
+    wave_lds_sync();
+    if (run) {
+        for (int k = lig; k < n; k += G) {
+            const int R = nfl + (lo + k) * m;
+            const int sc = max(comb[k], -(1 << 28)) - g * (R + nfr + ndb);
+            comb[k] = sc;
+            a.table[a.tab_off[r] + k] = sc;
+        }
+    }
+    wave_lds_sync();
+    if (act && first) {
+        bool certified = false;
+        if (run) {
+            SeenMask64 seen;
+            const int flags = a.end_flags;
+            auto ub = [&](int k) { return band_ub(geo, nfl, ntr, nfr, m, lo + k, flags); };
+            const CertResult cr = search_replay_cert(a.est_cn[r], a.step, a.lsr, a.max_iters, a.tie_last, comb, lo, n, seen, ub);
+            if (!cr.uncertain) {
+                certified = true;
+                a.spec[r] = make_int4(cr.res.cn, cr.res.score, cr.res.n_explored,
+                                      (cr.res.miss ? kSpecMiss : 0) | (cr.res.empty ? kSpecEmpty : 0));
+            }
+        }
+        if (!certified) {   // hand the read to the exact kernels (they run after this one)
+            const int c = classify(nfl, ntr, nfr, m, lo, n, 0, 0);
+            const int idx = atomicAdd(&a.counters[kCntClass0 + c], 1);
+            if (idx < a.list_stride) {
+                int32_t* gl = a.cls_list + (size_t)c * a.list_stride * 2;
+                gl[2 * idx] = r;
+                gl[2 * idx + 1] = 0;
+            } else {
+                atomicOr(&a.counters[kCntError], kErrScratch);
+            }
+            a.exact[r] = 1;
+            atomicAdd(&a.counters[kCntBandFallback], 1);
+            if (c != kGenericClass)
+                atomicAdd(a.cells, (unsigned long long)ndb * ((unsigned long long)nfl + (unsigned long long)(lo + n - 1) * m + nfr));
+        }
+    }
+    wave_lds_sync();
+}
+
+__global__ void __launch_bounds__(256) k_dp_band(KArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * kBandWaveLds + kLdsSlack];
+    __shared__ uint8_t s_enc[256];
+    __shared__ int8_t s_mat[kNSym * kNSym + 3];
+    s_enc[threadIdx.x] = c_enc[threadIdx.x];
+    for (int i = threadIdx.x; i < kNSym * kNSym; i += 256) s_mat[i] = c_mat[i / kNSym][i % kNSym];
+    __syncthreads();
+    uint8_t* const Lw = lds + (threadIdx.x >> 6) * kBandWaveLds;
+    const int n8 = min(a.counters[kCntClass0 + kBandClass0], a.list_stride);
+    const int n16 = min(a.counters[kCntClass0 + kBandClass0 + 1], a.list_stride);
+    const int ch16 = (n16 + 3) / 4, ch8 = (n8 + 7) / 8;
+    for (;;) {
+        int c = 0;
+        if ((threadIdx.x & 63) == 0) c = atomicAdd(&a.counters[kCntNextBand], 1);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c < ch16) band_wave<16>(a, c * 4, Lw, s_enc, s_mat);
+        else if (c < ch16 + ch8) band_wave<8>(a, (c - ch16) * 8, Lw, s_enc, s_mat);
+        else break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Long-read kernel: the same shared-prefix systolic DP for windows wider than the largest fast class
 // (BASELINE config 5: up to ~2 000 copies, |db| ~ 12 kb).  One read per wave (G = 64, CL = 28); the
 // db columns are cut into tiles of kLongTile slots that are processed one after the other, the
@@ -1233,9 +1576,24 @@ __global__ void __launch_bounds__(64) k_replay(KArgs a, ReplayArgs p) {
                 res.empty = (spec_flags & kSpecEmpty) ? 1 : 0;
             } else {
                 const int r = base + i;
+                const int rp = a.rep[r];
                 SeenMask64 seen;
-                res = search_replay(start, p.step, p.lsr, p.max_iters, p.tie_last, a.table + a.tab_off[r], a.win_lo[r],
-                                    min(a.win_n[r], 64), seen);
+                if (!a.band_mode || a.exact[rp]) {
+                    res = search_replay(start, p.step, p.lsr, p.max_iters, p.tie_last, a.table + a.tab_off[r], a.win_lo[r],
+                                        min(a.win_n[r], 64), seen);
+                } else {
+                    // banded table: lower bounds + certificate; an ambiguous comparison asks for exact scores
+                    const int nfl = a.nfl[rp], ntr = a.ntr[rp], nfr = a.nfr[rp];
+                    const int m = a.motif_off[l + 1] - a.motif_off[l];
+                    const int wlo = a.win_lo[r], wn = min(a.win_n[r], 64);
+                    const BandGeo geo = band_geometry(nfl, ntr, nfr, m, wlo, wn);
+                    const int flags = a.end_flags;
+                    auto ub = [&](int k) { return band_ub(geo, nfl, ntr, nfr, m, wlo + k, flags); };
+                    const CertResult cr = search_replay_cert(start, p.step, p.lsr, p.max_iters, p.tie_last,
+                                                             a.table + a.tab_off[r], wlo, wn, seen, ub);
+                    res = cr.res;
+                    if (cr.uncertain) { res.miss = 1; res.need_lo = wlo; res.need_hi = wlo + wn - 1; }
+                }
             }
             if (res.miss) {
                 if (lane == 0) {

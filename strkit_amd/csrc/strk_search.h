@@ -103,6 +103,170 @@ STRK_HD SearchResult search_replay(int32_t start, int32_t step, int32_t lsr, int
     return res;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Banded scoring with an exactness certificate (k_dp_band).
+//
+// The band kernel restricts the forward DP to the diagonals d = j - r in [dlo, dlo + Wd) and the
+// backward DP (over the reversed right flank) to delta = j' - k' in [bdlo, bdlo + Wd); what it returns
+// for candidate i, S_band[i], is the exact maximum over the alignments that stay inside both bands and
+// end by the normal rules, so S_band[i] <= S[i].  Every other alignment touches a diagonal outside one
+// of the bands (or belongs to one of the two free-end families the band kernel does not track), and an
+// alignment that touches diagonal d scores at most 2 * (number of cells on d): split it at a cell on d,
+// each half has no more diagonal moves than d has cells on that side, and reaching d from any other
+// start/end diagonal costs 5 per step while gaining at most 2.  Hence
+//     S[i] <= max(S_band[i], band_ub(i)),
+// and an entry with S_band[i] >= band_ub(i) is exact.  The search is replayed on (S_band, band_ub)
+// with search_replay_cert(); whenever a comparison could be changed by an inexact entry the read is
+// re-scored by the exact kernels.  BASELINE's band = 64/128/512 are widths at which HiFi reads of the
+// named configs certify; noisy (ONT-like) reads mostly do not and take the exact path.
+// ---------------------------------------------------------------------------------------------
+struct BandGeo {
+    int32_t ok;      // eligible for the band kernel
+    int32_t G;       // lanes per read: 8 (Wd = 128) or 16 (Wd = 256); 16 diagonals per lane
+    int32_t wd;      // band width in diagonals
+    int32_t dlo;     // forward band: d in [dlo, dlo + wd)
+    int32_t bdlo;    // backward band (reversed coordinates): delta in [bdlo, bdlo + wd)
+    int32_t cmin;    // first db node column the fork rows can touch
+    int32_t ncol;    // number of such columns: (n - 1) * m + wd
+};
+
+constexpr int kBandMaxDb8 = 400, kBandMaxDb16 = 1024;      // |db| limits of the two band classes (LDS)
+constexpr int kBandMaxCol8 = 320, kBandMaxCol16 = 512;     // fork-column limits
+constexpr int kBandMaxFlank = 127;
+constexpr int kBandRowSlack = 160;
+
+STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, int32_t lo, int32_t n) {
+    BandGeo b = {0, 0, 0, 0, 0, 0, 0};
+    const int64_t ndb = (int64_t)nfl + ntr + nfr;
+    if (nfl < 1 || nfr < 1 || nfr > kBandMaxFlank || m < 1 || m > 256 || n < 1 || n > 32) return b;
+    const int64_t e_lo = (int64_t)ntr - (int64_t)(lo + n - 1) * m, e_hi = (int64_t)ntr - (int64_t)lo * m;
+    const int64_t span_lo = e_lo < 0 ? e_lo : 0, span_hi = e_hi > 0 ? e_hi : 0;
+    int64_t smin = ndb >> 6;
+    if (smin < 12) smin = 12;
+    const int64_t need = span_hi - span_lo + 1 + 2 * smin;
+    const int32_t wd = need <= 128 ? 128 : (need <= 256 ? 256 : 0);
+    if (!wd) return b;
+    if ((int64_t)wd * 5 > (ndb + 1) * 4) return b;   // the band must drop at least a fifth of the columns
+    const int64_t rows = (int64_t)nfl + (int64_t)(lo + n - 1) * m;
+    const int64_t ncol = (int64_t)(n - 1) * m + wd;
+    if (wd == 128 && (ndb > kBandMaxDb8 || ncol > kBandMaxCol8 || rows > kBandMaxDb8 + kBandRowSlack)) return b;
+    if (wd == 256 && (ndb > kBandMaxDb16 || ncol > kBandMaxCol16 || rows > kBandMaxDb16 + kBandRowSlack)) return b;
+    const int64_t extra = wd - (span_hi - span_lo + 1);
+    b.ok = 1;
+    b.G = wd / 16;
+    b.wd = wd;
+    b.dlo = (int32_t)(span_lo - extra / 2);
+    b.bdlo = -(wd / 2);
+    b.cmin = (int32_t)(nfl + (int64_t)lo * m + b.dlo);
+    b.ncol = (int32_t)ncol;
+    return b;
+}
+
+STRK_HD int64_t band_diag_len(int64_t nc, int64_t ndb, int64_t d) {
+    int64_t v = d >= 0 ? (nc < ndb - d ? nc : ndb - d) : (nc + d < ndb ? nc + d : ndb);
+    return v < 0 ? 0 : v;
+}
+// longest diagonal among d >= d0 (resp. d <= d0)
+STRK_HD int64_t band_len_beyond_hi(int64_t nc, int64_t ndb, int64_t d0) { return d0 >= 0 ? band_diag_len(nc, ndb, d0) : (nc < ndb ? nc : ndb); }
+STRK_HD int64_t band_len_beyond_lo(int64_t nc, int64_t ndb, int64_t d0) { return d0 <= 0 ? band_diag_len(nc, ndb, d0) : (nc < ndb ? nc : ndb); }
+
+// Upper bound on the score of every alignment of candidate i the band kernel does not consider.
+STRK_HD int32_t band_ub(const BandGeo& b, int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, int32_t i, int32_t end_flags) {
+    const int64_t ndb = (int64_t)nfl + ntr + nfr, nc = (int64_t)nfl + (int64_t)i * m + nfr, R = (int64_t)nfl + (int64_t)i * m;
+    const int64_t e = ndb - nc;   // diagonal of the end corner
+    int64_t L = band_len_beyond_hi(nc, ndb, (int64_t)b.dlo + b.wd);            // right of the forward band
+    int64_t v = band_len_beyond_lo(nc, ndb, (int64_t)b.dlo - 1);              // left of it
+    if (v > L) L = v;
+    v = band_len_beyond_hi(nc, ndb, e - b.bdlo + 1);                          // backward band, original diagonals
+    if (v > L) L = v;
+    v = band_len_beyond_lo(nc, ndb, e - ((int64_t)b.bdlo + b.wd - 1) - 1);
+    if (v > L) L = v;
+    if (end_flags & 8) { v = band_len_beyond_hi(nc, ndb, ndb - R); if (v > L) L = v; }     // ends in the last column, row <= R_i
+    if (end_flags & 4) { v = band_len_beyond_lo(nc, ndb, -R - 1); if (v > L) L = v; }      // starts on the left edge below R_i
+    return (int32_t)(2 * L);
+}
+
+// search_replay on a banded table: scores[k] is a lower bound, ub(k) the bound on what the band kernel
+// ignored.  Identical to search_replay whenever it returns with uncertain == 0; uncertain == 1 means an
+// inexact entry could have changed a comparison (or been the maximum) and the read needs exact scores.
+struct CertResult {
+    SearchResult res;
+    int32_t uncertain;
+};
+
+template <class Seen, class Ub>
+STRK_HD CertResult search_replay_cert(int32_t start, int32_t step, int32_t lsr, int32_t max_iters, int32_t tie_last,
+                                      const int32_t* scores, int32_t lo, int32_t n, Seen& seen, const Ub& ub) {
+    CertResult out = {{0, 0, 0, 0, 0, 0, 0}, 0};
+    SearchResult& res = out.res;
+    int64_t st_size[4];
+    int32_t st_dir[4];
+    int sp = 0;
+    st_size[sp] = (int64_t)start - step; st_dir[sp++] = -1;
+    st_size[sp] = (int64_t)start + step; st_dir[sp++] = 1;
+    st_size[sp] = start;                 st_dir[sp++] = 0;
+    bool have_best = false;
+    int32_t best_i = 0, best_s = 0, n_scored = 0;
+    int32_t max_inexact = -(1 << 30);   // largest upper bound among the inexact entries scored so far
+    const bool widen = step > lsr;
+    while (sp > 0 && n_scored < max_iters) {
+        --sp;
+        const int64_t size = st_size[sp];
+        const int32_t dir = st_dir[sp];
+        if (size < 0) continue;
+        int64_t w_lo = size - ((dir < 1 || widen) ? lsr : 0);
+        if (w_lo < 0) w_lo = 0;
+        const int64_t w_hi = size + ((dir > -1 || widen) ? lsr : 0);
+        if (w_lo < lo || w_hi >= (int64_t)lo + n) {
+            res.miss = 1;
+            res.need_lo = (int32_t)w_lo;
+            res.need_hi = (int32_t)w_hi;
+            return out;
+        }
+        bool have_mv = false;
+        int64_t mv_i = 0;
+        int32_t mv_s = 0, win_inexact = -(1 << 30);
+        for (int64_t i = w_lo; i <= w_hi; ++i) {
+            const int32_t k = (int32_t)(i - lo);
+            const int32_t s = scores[k];
+            const int32_t u = ub(k);
+            const bool exact = s >= u;
+            if (!seen.test(k)) {
+                seen.set(k);
+                ++n_scored;
+                if (exact) {
+                    if (!have_best || s > best_s || (tie_last && s == best_s)) { have_best = true; best_i = (int32_t)i; best_s = s; }
+                } else if (u > max_inexact) {
+                    max_inexact = u;
+                }
+            }
+            if (exact) {
+                if (!have_mv || s > mv_s || (tie_last && s == mv_s)) { have_mv = true; mv_i = i; mv_s = s; }
+            } else if (u > win_inexact) {
+                win_inexact = u;
+            }
+        }
+        // the window's maximum must be an exact entry that no inexact one can reach or tie
+        if (!have_mv || win_inexact >= mv_s) { out.uncertain = 1; return out; }
+        if (mv_i > size) {
+            const int64_t nr = mv_i + step;
+            const bool in_tab = nr >= lo && nr < (int64_t)lo + n;
+            if (nr >= 0 && !(in_tab && seen.test((int32_t)(nr - lo)))) { st_size[sp] = nr; st_dir[sp++] = 1; }
+        }
+        if (mv_i < size) {
+            const int64_t nr = mv_i - step;
+            const bool in_tab = nr >= lo && nr < (int64_t)lo + n;
+            if (nr >= 0 && !(in_tab && seen.test((int32_t)(nr - lo)))) { st_size[sp] = nr; st_dir[sp++] = -1; }
+        }
+    }
+    res.n_explored = n_scored;
+    if (n_scored == 0) { res.empty = 1; return out; }
+    if (!have_best || max_inexact >= best_s) { out.uncertain = 1; return out; }
+    res.cn = best_i;
+    res.score = best_s;
+    return out;
+}
+
 struct SeenMask64 {
     uint64_t m = 0;
     STRK_HD bool test(int k) const { return (m >> k) & 1; }

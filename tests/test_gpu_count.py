@@ -112,3 +112,33 @@ def test_expansion_stress_long_reads(gpu_ctx):
     got, st = _run(b, gpu_ctx)
     _compare(b, got, oracle_count(b))
     assert st["n_fallback"] == 0
+
+
+def test_band_kernel_certifies_hifi_and_falls_back_on_noise(gpu_ctx):
+    """k_dp_band: lower bounds + certificate.  HiFi reads certify, noisy reads are re-scored exactly; the
+    answers never differ from the exact kernels'."""
+    b = make_config(2, n_loci=120)
+    exp = oracle_count(b)
+    got, st = _run(b, gpu_ctx)
+    _compare(b, got, exp)
+    assert st["n_band_reads"] > b.n_reads // 4, st
+    assert st["n_band_fallback"] < st["n_band_reads"] // 5, st
+    got0, st0 = _run(b, gpu_ctx, band=False)
+    _compare(b, got0, exp)
+    assert st0["n_band_reads"] == 0
+    # ONT-like noise: mostly uncertified -> exact path; results identical
+    b3 = make_config(3, n_loci=60, motif_len=(2, 6), cn_range=(30, 60))
+    got3, st3 = _run(b3, gpu_ctx)
+    _compare(b3, got3, oracle_count(b3))
+    # low-complexity windows (many off-band matches) with bad estimates and a narrow speculative window
+    rng = np.random.default_rng(25)
+    loci = []
+    for _ in range(40):
+        motif, reads = random_locus(rng, 6, motif_len=(1, 4), cn=(30, 70), flank=(60, 70), alpha="AC", edits=(0, 3))
+        loci.append((motif, reads))
+    bl = LocusBatch.from_reads(loci)
+    bl.est_cn = np.maximum(0, bl.est_cn + rng.integers(-3, 4, size=bl.n_reads)).astype(np.int32)
+    expl = oracle_count(bl)
+    for window in (0, 4):
+        gotl, stl = _run(bl, gpu_ctx, window=window)
+        _compare(bl, gotl, expl)
