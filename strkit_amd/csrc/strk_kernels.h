@@ -1135,6 +1135,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
 }
 
 __global__ void __launch_bounds__(256) k_dp_band(KArgs a) {
+    if (a.counters[kCntClass0 + kBandClass0] + a.counters[kCntClass0 + kBandClass0 + 1] <= 0) return;
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * kBandWaveLds + kLdsSlack];
     __shared__ uint8_t s_enc[256];
     __shared__ int8_t s_mat[kNSym * kNSym + 3];
@@ -1178,6 +1179,7 @@ static_assert(LongLayout::BYTES <= kWaveLdsBytes, "k_dp_long fits the per-wave L
 
 __global__ void __launch_bounds__(256) k_dp_long(KArgs a) {
     constexpr int g = kGap, G = 64, NQ = 7, CL = 28, TW = kLongTile;
+    if (a.counters[kCntClass0 + kLongClass] <= 0) return;   // nothing long in this batch (the usual case)
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * kWaveLdsBytes + kLdsSlack];
     __shared__ uint8_t s_enc[256];
     __shared__ int8_t s_mat[kNSym * kNSym + 3];
@@ -1463,6 +1465,7 @@ __global__ void __launch_bounds__(256) k_dp_long(KArgs a) {
 // ---------------------------------------------------------------------------------------------
 __global__ void k_dp_generic(KArgs a) {
     const int count = min(a.counters[kCntClass0 + kGenericClass], a.list_stride);
+    if (count <= 0) return;
     const int32_t* list = a.cls_list + (size_t)kGenericClass * a.list_stride * 2;
     const bool dbBeg = a.end_flags & 1, dbEnd = a.end_flags & 2, cBeg = a.end_flags & 4, cEnd = a.end_flags & 8;
     constexpr int g = kGap;

@@ -144,13 +144,18 @@ STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, 
     int64_t smin = ndb >> 6;
     if (smin < 12) smin = 12;
     const int64_t need = span_hi - span_lo + 1 + 2 * smin;
-    const int32_t wd = need <= 128 ? 128 : (need <= 256 ? 256 : 0);
+    const int64_t rows = (int64_t)nfl + (int64_t)(lo + n - 1) * m;
+    int32_t wd = 0;
+    for (int32_t w = 128; w <= 256 && !wd; w *= 2) {   // narrowest class that holds the band and the window in LDS
+        if (need > w) continue;
+        const int64_t ncol_w = (int64_t)(n - 1) * m + w;
+        const bool fits = w == 128 ? (ndb <= kBandMaxDb8 && ncol_w <= kBandMaxCol8 && rows <= kBandMaxDb8 + kBandRowSlack)
+                                   : (ndb <= kBandMaxDb16 && ncol_w <= kBandMaxCol16 && rows <= kBandMaxDb16 + kBandRowSlack);
+        if (fits) wd = w;
+    }
     if (!wd) return b;
     if ((int64_t)wd * 5 > (ndb + 1) * 4) return b;   // the band must drop at least a fifth of the columns
-    const int64_t rows = (int64_t)nfl + (int64_t)(lo + n - 1) * m;
     const int64_t ncol = (int64_t)(n - 1) * m + wd;
-    if (wd == 128 && (ndb > kBandMaxDb8 || ncol > kBandMaxCol8 || rows > kBandMaxDb8 + kBandRowSlack)) return b;
-    if (wd == 256 && (ndb > kBandMaxDb16 || ncol > kBandMaxCol16 || rows > kBandMaxDb16 + kBandRowSlack)) return b;
     const int64_t extra = wd - (span_hi - span_lo + 1);
     b.ok = 1;
     b.G = wd / 16;
