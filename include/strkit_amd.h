@@ -103,11 +103,15 @@ typedef struct strk_stats {
     int32_t n_miss_reads;  /* reads whose search left the speculative window (re-scored) */
     int32_t n_miss_rounds; /* extra launch rounds needed to resolve them */
     float kernel_ms;       /* HIP-event time of the device work of this call */
-    float dp_kernel_ms;    /* ... of the DP kernels alone */
+    float dp_kernel_ms;    /* ... of the exact DP kernel (k_dp_all) alone */
     int32_t n_dp_launches;
     int32_t n_dedup_reads; /* reads served by the score table of an identical earlier read */
     int32_t n_band_reads;  /* reads scored by the banded kernel ... */
     int32_t n_band_fallback; /* ... of which the certificate failed (re-scored by the exact kernels) */
+    float band_kernel_ms;  /* HIP-event time of the banded kernel (k_dp_band) of this call */
+    int32_t reserved;
+    int64_t band_bytes;    /* algorithmic bytes (|window| + 16 per read) of the reads k_plan routed to k_dp_band */
+    int64_t exact_bytes;   /* ... and to the exact kernels (k_dp_all / k_dp_long / generic) */
 } strk_stats;
 
 int strk_init(int device, strk_ctx** out);

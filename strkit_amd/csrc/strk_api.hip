@@ -86,7 +86,7 @@ struct strk_ctx {
     DevBuf in_seqs, in_seq_off, in_nfl, in_ntr, in_nfr, in_est, in_read_off, in_motifs, in_motif_off;
     DevBuf out_cn, out_score, out_n, out_start;
     int32_t* h_counters = nullptr;  // pinned: counters + cells + scratch_used
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // call start, exact DP start/end, call end, band start/end
     size_t scratch_ints = 0;
     int band_cooldown = 0;   // > 0: the band kernel is switched off for that many calls (too many certificates failed)
     // one submitted-but-not-finished batched call (strk_submit_loci_device .. strk_finish)
@@ -112,7 +112,7 @@ constexpr size_t kLongSlotInts = (size_t)48 << 10;
 constexpr size_t kScratchInts = kLongWaves * kLongSlotInts + ((size_t)16 << 20);
 // device layout of the `counters` buffer: int32[kCntTotal] | pad | u64 cells | u64 scratch_used
 constexpr size_t kCellsOff = 64 * sizeof(int32_t);
-constexpr size_t kCountersBytes = kCellsOff + 2 * sizeof(unsigned long long);
+constexpr size_t kCountersBytes = kCellsOff + 4 * sizeof(unsigned long long);   // cells, scratch_used, band bytes, exact bytes
 
 int check_params(const strk_params* p, strk_params* out) {
     if (!p) return fail(STRK_E_INVALID, "params is NULL");
@@ -190,16 +190,21 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
 void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_items, int n_items, int force_generic,
                      hipStream_t st, bool time_dp) {
     hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, a, mode, d_items, n_items, force_generic);
+    static const int tune = getenv("STRKIT_AMD_DP_BLOCKS") ? atoi(getenv("STRKIT_AMD_DP_BLOCKS")) : 0;   // tuning aid
+    // a call that shares the device with other calls in flight takes half the CU slots per kernel, so that the
+    // tail of one call and the head of the next co-run (this call is counted already)
+    const int share = g_calls_in_flight.load(std::memory_order_relaxed) > 1 ? 2 : 1;
     if (a.band_mode && mode == 0 && !force_generic) {
         // banded first pass: certified reads are done, the others are appended to the exact lists below
-        hipLaunchKernelGGL(k_dp_band, dim3(256 * kBandBlocksPerCU), dim3(256), 0, st, a);
+        const int blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU / share, (a.list_stride + 3) / 4));
+        if (time_dp) (void)hipEventRecord(c->ev[4], st);
+        hipLaunchKernelGGL(k_dp_band, dim3(blocks), dim3(256), 0, st, a);
+        if (time_dp) (void)hipEventRecord(c->ev[5], st);
     }
     if (time_dp) (void)hipEventRecord(c->ev[1], st);
     if (!force_generic) {
         // persistent-style grid: every wave pulls chunks from the device-side queue until it is empty
         constexpr int kBlocksPerCU = std::max(1, std::min(8, (160 * 1024) / (4 * kWaveLdsBytes + kLdsSlack + 1024)));
-        static const int tune = getenv("STRKIT_AMD_DP_BLOCKS") ? atoi(getenv("STRKIT_AMD_DP_BLOCKS")) : 0;   // tuning aid
-        const int share = g_calls_in_flight.load(std::memory_order_relaxed) > 1 ? 2 : 1;   // this call is counted already
         const int blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBlocksPerCU / share, (a.list_stride + 3) / 4));
         if (a.ref_mode) hipLaunchKernelGGL(k_dp_ref, dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);
@@ -458,6 +463,12 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) stats->kernel_ms = ms;
         if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) stats->dp_kernel_ms = ms;
+        if (c->p_args.band_mode && hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) stats->band_kernel_ms = ms;
+        {
+            const unsigned long long* u = reinterpret_cast<const unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
+            stats->band_bytes = (int64_t)u[2];
+            stats->exact_bytes = (int64_t)u[3];
+        }
         stats->n_dp_launches = 2;
         stats->n_fallback = c->h_counters[kCntClass0 + kGenericClass];
         stats->n_dedup_reads = c->h_counters[kCntDup];
@@ -761,7 +772,7 @@ int strk_init(int device, strk_ctx** out) {
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(strk::c_mat), t.mat, sizeof t.mat);
     if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(strk::c_enc), t.enc, sizeof t.enc);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), kCountersBytes, hipHostMallocDefault);
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
     if (e != hipSuccess) {
         strk_destroy(c);
         return fail(STRK_E_DEVICE, "context setup: %s", hipGetErrorString(e));

@@ -77,7 +77,8 @@ struct KArgs {
     int32_t* table;       // score table
     int32_t* cls_list;    // [kNumLists * list_stride * 2]  (read, chunk start) pairs
     int32_t* counters;    // see Counter enum
-    unsigned long long* cells;  // DP cells executed
+    unsigned long long* cells;  // DP cells executed; cells[2] / cells[3]: algorithmic bytes (|window| + 16 per read) of the
+                                // items routed to the band kernel / to the exact kernels by k_plan
     int32_t* scratch;     // generic kernel rows
     long long scratch_cap;      // in int32 units; [0, long_waves * long_slot) belongs to k_dp_long (one slot
                                 //   per resident wave), the rest is handed out by the generic kernel's bump allocator
@@ -187,9 +188,9 @@ __device__ inline bool same_read(const KArgs& a, int r, int q) {
 __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* items, int n_items, int force_generic) {
     __shared__ int s_cnt[kNumLists];
     __shared__ int s_base[kNumLists];
-    __shared__ unsigned long long s_cells;
+    __shared__ unsigned long long s_cells, s_bytes_band, s_bytes_exact;
     if (threadIdx.x < kNumLists) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_cells = 0;
+    if (threadIdx.x == 0) { s_cells = 0; s_bytes_band = 0; s_bytes_exact = 0; }
     __syncthreads();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int r = 0, nfl = 0, ntr = 0, nfr = 0, m = 1, lo = 0, n = 0;
@@ -260,14 +261,21 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
             cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
         }
     }
-    if (cells) atomicAdd(&s_cells, cells);
+    if (cells) {
+        atomicAdd(&s_cells, cells);
+        atomicAdd(band_list >= 0 ? &s_bytes_band : &s_bytes_exact, ndb + 16);
+    }
     __syncthreads();
     if (threadIdx.x < kNumLists) {
         const int c = threadIdx.x;
         s_base[c] = s_cnt[c] ? atomicAdd(&a.counters[kCntClass0 + c], s_cnt[c]) : 0;
         s_cnt[c] = 0;
     }
-    if (threadIdx.x == 0 && s_cells) atomicAdd(a.cells, s_cells);
+    if (threadIdx.x == 0 && s_cells) {
+        atomicAdd(a.cells, s_cells);
+        if (s_bytes_band) atomicAdd(a.cells + 2, s_bytes_band);
+        if (s_bytes_exact) atomicAdd(a.cells + 3, s_bytes_exact);
+    }
     __syncthreads();
     for (int k0 = 0; k0 < n; k0 += kTableMax) {
         const int nn = min(kTableMax, n - k0);
