@@ -847,16 +847,20 @@ static_assert(class_G(kNumClasses - 1) == 64 && class_CL(kNumClasses - 1) == 28,
 // The backward pass is the same function on the reversed right flank and the reversed window.
 // ---------------------------------------------------------------------------------------------
 struct BandLayout {
+    // class-byte array: selb[pad + x] <-> db[x]; `pad` selector-0x0c bytes in front and pad + kBandHiPad
+    // behind, sized so that no column the two passes can ask for (virtual rows, rows beyond |db|, the
+    // two-step prefetch) falls outside it: the hot loop indexes it without clamping.
     int wd, pad, maxdb, off_sel, off_cp, off_ct, off_b0, group_bytes, sel_len;
     static constexpr int OFF_TBL = 0, OFF_COMB = 18 * 8, OFF_MISC = OFF_COMB + kTableMax * 4;
+    static constexpr int kBandHiPad = kBandRowSlack + 32;
     __host__ __device__ constexpr BandLayout(int G)
         : wd(16 * G), pad(16 * G + G + 8), maxdb(G == 8 ? kBandMaxDb8 : kBandMaxDb16),
           off_sel(OFF_MISC + 16),
-          off_cp(off_sel + ((maxdb + 2 * (16 * G + G + 8) + 15) & ~15)),
+          off_cp(off_sel + ((maxdb + 2 * (16 * G + G + 8) + kBandHiPad + 15) & ~15)),
           off_ct(off_cp + ((maxdb + kBandRowSlack + 2 * G + 4 + 15) & ~15)),
           off_b0(off_ct + ((kBandMaxFlank + 2 * G + 4 + 15) & ~15)),
           group_bytes(off_b0 + (((G == 8 ? kBandMaxCol8 : kBandMaxCol16) * 2 + 15) & ~15)),
-          sel_len(maxdb + 2 * (16 * G + G + 8)) {}
+          sel_len((maxdb + 2 * (16 * G + G + 8) + kBandHiPad) & ~3) {}
 };
 constexpr int kBandWaveLds = (8 * BandLayout(8).group_bytes > 4 * BandLayout(16).group_bytes) ? 8 * BandLayout(8).group_bytes
                                                                                              : 4 * BandLayout(16).group_bytes;
@@ -882,8 +886,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     const int d0 = dlo_ + x.lig * 16;                 // diagonal of this lane's slot 0
     auto g0 = [&](int j) -> int { return topFree ? g * min(max(j, 0), ncols) : 0; };   // row-0 pattern
     auto col_addr = [&](int j) -> int {               // LDS index of the class byte of column j (1-based)
-        const int idx = BWD ? x.pad + ncols - j : x.pad + j - 1;
-        return min(max(idx, 0), x.maxidx);
+        return BWD ? x.pad + ncols - j : x.pad + j - 1;   // always inside the padded array (BandLayout)
     };
     int Ha[16], Hb[16];
     unsigned sel[4];

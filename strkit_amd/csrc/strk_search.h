@@ -130,10 +130,10 @@ struct BandGeo {
     int32_t ncol;    // number of such columns: (n - 1) * m + wd
 };
 
-constexpr int kBandMaxDb8 = 400, kBandMaxDb16 = 1024;      // |db| limits of the two band classes (LDS)
+constexpr int kBandMaxDb8 = 384, kBandMaxDb16 = 1024;      // |db| limits of the two band classes (LDS)
 constexpr int kBandMaxCol8 = 320, kBandMaxCol16 = 512;     // fork-column limits
 constexpr int kBandMaxFlank = 127;
-constexpr int kBandRowSlack = 160;
+constexpr int kBandRowSlack = 96;    // prefix rows a band item may have beyond |db|
 
 STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, int32_t lo, int32_t n) {
     BandGeo b = {0, 0, 0, 0, 0, 0, 0};
