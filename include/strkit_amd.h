@@ -74,7 +74,7 @@ typedef struct strk_params {
                                    1: score every read separately */
     int32_t no_band;            /* 0 (default): reads whose window is much wider than the band the search can
                                    reach are scored by the banded kernel first and re-scored exactly only when
-                                   the exactness certificate fails (DESIGN.md §3.9); 1: exact kernels only */
+                                   the exactness certificate fails (DESIGN.md §3, item 8); 1: exact kernels only */
     int32_t reserved;
 } strk_params;
 

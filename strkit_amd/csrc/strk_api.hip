@@ -200,6 +200,7 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
         if (time_dp) (void)hipEventRecord(c->ev[4], st);
         hipLaunchKernelGGL(k_dp_band, dim3(blocks), dim3(256), 0, st, a);
         if (time_dp) (void)hipEventRecord(c->ev[5], st);
+        hipLaunchKernelGGL(k_dp_band_wide, dim3(blocks), dim3(256), 0, st, a);   // long windows (exits at once if none)
     }
     if (time_dp) (void)hipEventRecord(c->ev[1], st);
     if (!force_generic) {
@@ -472,12 +473,14 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         stats->n_dp_launches = 2;
         stats->n_fallback = c->h_counters[kCntClass0 + kGenericClass];
         stats->n_dedup_reads = c->h_counters[kCntDup];
-        stats->n_band_reads = c->h_counters[kCntClass0 + kBandClass0] + c->h_counters[kCntClass0 + kBandClass0 + 1];
+        stats->n_band_reads = 0;
+        for (int k = 0; k < kNumBandClasses; ++k) stats->n_band_reads += c->h_counters[kCntClass0 + kBandClass0 + k];
         stats->n_band_fallback = c->h_counters[kCntBandFallback];
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
     }
     {   // adaptive: noisy reads mostly fail the certificate and pay for both passes
-        const int nb = c->h_counters[kCntClass0 + kBandClass0] + c->h_counters[kCntClass0 + kBandClass0 + 1];
+        int nb = 0;
+        for (int k = 0; k < kNumBandClasses; ++k) nb += c->h_counters[kCntClass0 + kBandClass0 + k];
         if (c->band_cooldown > 0) --c->band_cooldown;
         else if (nb >= 64 && 2 * c->h_counters[kCntBandFallback] > nb) c->band_cooldown = 32;
     }

@@ -48,8 +48,8 @@ __host__ __device__ constexpr int class_CL(int c) {
 __host__ __device__ constexpr int class_cap(int c) { return class_G(c) * class_CL(c); }
 constexpr int kLongClass = kNumClasses;         // list of the column-tiled long-read kernel (k_dp_long)
 constexpr int kGenericClass = kNumClasses + 1;  // list of the generic kernel
-constexpr int kBandClass0 = kNumClasses + 2;    // band kernel lists: +0 -> G = 8 (128 diagonals), +1 -> G = 16 (256)
-constexpr int kNumLists = kNumClasses + 4;
+constexpr int kBandClass0 = kNumClasses + 2;    // band kernel lists: + class (G = 8 << class lanes, 16 G diagonals)
+constexpr int kNumLists = kNumClasses + 2 + kNumBandClasses;
 constexpr int kLongTile = 64 * 28;              // slots per column tile of k_dp_long (G = 64, CL = 28)
 constexpr int kLongMaxTiles = 64;               // |db| + 1 <= 114 688
 constexpr int kLongFlankMax = 255;              // k_dp_long keeps both flanks' row symbols in LDS
@@ -106,9 +106,9 @@ enum Counter {
     kCntNextChunk = kNumLists + 2,        // work queue head of k_dp_all
     kCntDup = kNumLists + 3,              // reads that share the score table of an identical earlier read
     kCntNextLong = kNumLists + 4,         // work queue head of k_dp_long
-    kCntNextBand = kNumLists + 5,         // work queue head of k_dp_band
-    kCntBandFallback = kNumLists + 6,     // band reads whose search could not be certified (re-scored exactly)
-    kCntTotal = kNumLists + 7
+    kCntNextBand = kNumLists + 5,         // work queue heads of k_dp_band (+0) and k_dp_band_wide (+1)
+    kCntBandFallback = kNumLists + 7,     // band reads whose search could not be certified (re-scored exactly)
+    kCntTotal = kNumLists + 8
 };
 constexpr int kErrBadInput = 1;   // empty motif / negative length
 constexpr int kErrScratch = 2;    // generic scratch exhausted
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     int band_list = -1;   // >= 0: the read goes to the band kernel first
     if (a.band_mode && mode == 0 && n > 0 && n <= kTableMax && !force_generic) {
         const BandGeo geo = band_geometry(nfl, ntr, nfr, m, lo, n);
-        if (geo.ok) band_list = kBandClass0 + (geo.G == 16 ? 1 : 0);
+        if (geo.ok) band_list = kBandClass0 + geo.cls;
     }
     if (a.exact && gid < n_items && n > 0) a.exact[r] = band_list < 0;
     for (int k0 = 0; k0 < n; k0 += kTableMax) {
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
         if (c == kGenericClass) {
             for (int k = 0; k < nn; ++k) cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + k) * m + nfr);
         } else if (band_list >= 0) {
-            cells += (unsigned long long)(band_list == kBandClass0 ? 128 : 256) * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
+            cells += (unsigned long long)(128 << (band_list - kBandClass0)) * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
         } else {
             cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
         }
@@ -850,20 +850,24 @@ struct BandLayout {
     // class-byte array: selb[pad + x] <-> db[x]; `pad` selector-0x0c bytes in front and pad + kBandHiPad
     // behind, sized so that no column the two passes can ask for (virtual rows, rows beyond |db|, the
     // two-step prefetch) falls outside it: the hot loop indexes it without clamping.
-    int wd, pad, maxdb, off_sel, off_cp, off_ct, off_b0, group_bytes, sel_len;
-    static constexpr int OFF_TBL = 0, OFF_COMB = 18 * 8, OFF_MISC = OFF_COMB + kTableMax * 4;
+    int wd, pad, maxdb, maxcol, off_sel, off_cp, off_ct, off_b0, group_bytes, sel_len;
+    static constexpr int OFF_TBL = 0, OFF_COMB = 18 * 8, OFF_MISC = OFF_COMB + kTableMax * 4, OFF_LMAX = OFF_MISC + 16;
     static constexpr int kBandHiPad = kBandRowSlack + 32;
-    __host__ __device__ constexpr BandLayout(int G)
-        : wd(16 * G), pad(16 * G + G + 8), maxdb(G == 8 ? kBandMaxDb8 : kBandMaxDb16),
-          off_sel(OFF_MISC + 16),
-          off_cp(off_sel + ((maxdb + 2 * (16 * G + G + 8) + kBandHiPad + 15) & ~15)),
-          off_ct(off_cp + ((maxdb + kBandRowSlack + 2 * G + 4 + 15) & ~15)),
-          off_b0(off_ct + ((kBandMaxFlank + 2 * G + 4 + 15) & ~15)),
-          group_bytes(off_b0 + (((G == 8 ? kBandMaxCol8 : kBandMaxCol16) * 2 + 15) & ~15)),
-          sel_len((maxdb + 2 * (16 * G + G + 8) + kBandHiPad) & ~3) {}
+    __host__ __device__ constexpr BandLayout(int c)   // c = band class
+        : wd(128 << c), pad((128 << c) + (8 << c) + 8), maxdb(band_max_db(c)), maxcol(band_max_col(c)),
+          off_sel(OFF_LMAX + (band_class_fly(c) ? kTableMax * 4 : 0)),
+          off_cp(off_sel + ((band_max_db(c) + 2 * ((128 << c) + (8 << c) + 8) + kBandHiPad + 15) & ~15)),
+          // forward row symbols: the whole prefix (classes 0, 1) or 256 flank + 256 motif symbols (2, 3)
+          off_ct(off_cp + (band_class_fly(c) ? 512 : ((band_max_db(c) + kBandRowSlack + 2 * (8 << c) + 4 + 15) & ~15))),
+          off_b0(off_ct + ((kBandMaxFlank + 2 * (8 << c) + 4 + 15) & ~15)),
+          group_bytes(off_b0 + ((band_max_col(c) * 2 + 15) & ~15)),
+          sel_len((band_max_db(c) + 2 * ((128 << c) + (8 << c) + 8) + kBandHiPad) & ~3) {}
 };
-constexpr int kBandWaveLds = (8 * BandLayout(8).group_bytes > 4 * BandLayout(16).group_bytes) ? 8 * BandLayout(8).group_bytes
-                                                                                             : 4 * BandLayout(16).group_bytes;
+__host__ __device__ constexpr int band_wave_lds(int c) { return (64 / (8 << c)) * BandLayout(c).group_bytes; }
+__host__ __device__ constexpr int max_band_wave_lds(int c) {
+    return c < 0 ? 0 : (band_wave_lds(c) > max_band_wave_lds(c - 1) ? band_wave_lds(c) : max_band_wave_lds(c - 1));
+}
+constexpr int kBandWaveLds = max_band_wave_lds(kNumBandClasses - 1);
 constexpr int kBandNeg16 = -20000;
 
 struct BandCtx {
@@ -872,15 +876,18 @@ struct BandCtx {
     const uint2* tbl;
     const uint8_t* selb;   // class-byte array: selb[pad + x] <-> db[x], 0x0c elsewhere
     int pad, maxidx, ndb;
+    const uint8_t* flL;    // on-the-fly forward rows: 256 left-flank symbols, 256 motif symbols
+    const uint8_t* motifL;
+    int nfl, m;
 };
 
 // One banded pass over `nrows` rows.  BWD = false: forward pass (columns = db, left to right);
 // BWD = true: backward pass in reversed coordinates (columns = reversed db).  dlo_ is the first
 // diagonal of the band, topFree/leftFree the free-end flags of the top row / left column.
-template <int G, bool BWD>
+template <int G, bool BWD, bool FLY>
 __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsym, int nrows, int dlo_, bool topFree,
                                           bool leftFree, int nEff, int fork0, int m, int cmin, int ncol, int* comb,
-                                          short* b0col) {
+                                          short* b0col, int* lmaxA) {
     constexpr int g = kGap;
     const int ncols = x.ndb;
     const int d0 = dlo_ + x.lig * 16;                 // diagonal of this lane's slot 0
@@ -911,15 +918,31 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     if (BWD) forkG = g * nrows;                        // the backward pass has one event: its last row
     int forkIdx = 0;
     const int gm = g * m;
+    // wide classes (FLY): running maximum of the last column over the in-band rows.  Right of column |db|
+    // the pads replicate G(r, |db|), so from row |db| - dhi on the last lane's slot 15 holds that value.
+    int lastmax = kNegInf;
+    const int grFirst = g * max(1, ncols - dhi_);
+    // row symbols: staged in LDS with G-1 null rows in front (pa[t] is this lane's row at step t), or
+    // generated two steps ahead from the left flank and the motif phase (long windows)
     const uint8_t* pa = rowsym + (G - 1) - x.lig;
-    uint2 wordNext = x.tbl[pa[0]];
-    unsigned symNext = pa[1];
+    int rowi = -x.lig, ph = 0;
+    auto next_sym = [&]() -> unsigned {
+        unsigned sym = kNullSym;
+        if (rowi >= 0) sym = rowi < x.nfl ? x.flL[rowi] : x.motifL[ph];
+        if (rowi >= x.nfl) { ++ph; if (ph == x.m) ph = 0; }
+        ++rowi;
+        return sym;
+    };
+    uint2 wordNext;
+    unsigned symNext;
+    if (FLY) { wordNext = x.tbl[next_sym()]; symNext = next_sym(); }
+    else { wordNext = x.tbl[pa[0]]; symNext = pa[1]; }
     unsigned nbNext = x.selb[col_addr(jb + 16)];       // class byte entering at the next row
 #define STRK_BAND_STEP(SRC, DST, TT)                                                               \
     {                                                                                              \
         const uint2 word = wordNext;                                                               \
         wordNext = x.tbl[symNext];                                                                 \
-        symNext = pa[(TT) + 2];                                                                    \
+        symNext = FLY ? next_sym() : (unsigned)pa[(TT) + 2];                                       \
         const unsigned nb = nbNext;                                                                \
         nbNext = x.selb[col_addr(jb + 17)];                                                        \
         /* lane 0 works on row TT+1; left of the band lies the left boundary while j-1 <= 0 */      \
@@ -940,6 +963,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         }                                                                                          \
         DST[15] = max(max(upEdge, DST[14]), SRC[15] + (int)(w3 >> 24));                            \
         houtL = DST[15];                                                                           \
+        if (FLY && !BWD) lastmax = (gr + g >= grFirst) ? max(lastmax, houtL - (gr + g)) : lastmax;  \
         sel[0] = __builtin_amdgcn_alignbyte(sel[1], sel[0], 1);                                    \
         sel[1] = __builtin_amdgcn_alignbyte(sel[2], sel[1], 1);                                    \
         sel[2] = __builtin_amdgcn_alignbyte(sel[3], sel[2], 1);                                    \
@@ -959,6 +983,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
                 _Pragma("unroll") for (int k = 0; k < 16; k += 2)                                  \
                     acc = max(max(acc, DST[k] + (int)bc[k]), DST[k + 1] + (int)bc[k + 1]);         \
                 atomicMax(&comb[forkIdx], acc);                                                    \
+                if (FLY && x.last) lmaxA[forkIdx] = lastmax;                                       \
                 ++forkIdx;                                                                         \
                 forkG = forkIdx < nEff ? forkG + gm : 0x7fffffff;                                  \
             }                                                                                      \
@@ -972,12 +997,13 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
 #undef STRK_BAND_STEP
 }
 
-// Processes 64/G band items of list kBandClass0 + (G == 16), one per group.
-template <int G>
+// Processes 64/G items of band class BC (G = 8 << BC lanes per read), one per group.
+template <int BC>
 __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw, const uint8_t* s_enc, const int8_t* s_mat) {
-    constexpr int g = kGap;
-    constexpr BandLayout lay(G);
-    const int cls = kBandClass0 + (G == 16 ? 1 : 0);
+    constexpr int g = kGap, G = 8 << BC;
+    constexpr bool FLY = band_class_fly(BC);
+    constexpr BandLayout lay(BC);
+    const int cls = kBandClass0 + BC;
     const int lane = threadIdx.x & 63;
     const int lig = lane & (G - 1);
     const int grp = lane / G;
@@ -986,11 +1012,12 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
     uint2* const tbl = reinterpret_cast<uint2*>(Lg + BandLayout::OFF_TBL);
     int* const comb = reinterpret_cast<int*>(Lg + BandLayout::OFF_COMB);
     int* const misc = reinterpret_cast<int*>(Lg + BandLayout::OFF_MISC);
+    int* const lmaxA = reinterpret_cast<int*>(Lg + BandLayout::OFF_LMAX);   // wide classes only
     uint8_t* const selb = Lg + lay.off_sel;
-    uint8_t* const cp = Lg + lay.off_cp;
+    uint8_t* const cp = Lg + lay.off_cp;       // staged prefix rows, or (FLY) 256 flank + 256 motif symbols
     uint8_t* const ct = Lg + lay.off_ct;
     short* const b0col = reinterpret_cast<short*>(Lg + lay.off_b0);
-    uint8_t* const motifL = Lg + lay.off_b0;   // the motif sits there until the band columns are initialised
+    uint8_t* const motifL = FLY ? cp + 256 : Lg + lay.off_b0;   // non-FLY: the motif sits in b0col until that is initialised
 
     const int count = min(a.counters[kCntClass0 + cls], a.list_stride);
     const int32_t* list = a.cls_list + (size_t)cls * a.list_stride * 2;
@@ -1057,19 +1084,23 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
         }
         tbl[e] = make_uint2(wlo, whi);
     }
-    for (int e = lig; e < kTableMax; e += G) comb[e] = kNegInf;
+    for (int e = lig; e < kTableMax; e += G) { comb[e] = kNegInf; if (FLY) lmaxA[e] = kNegInf; }
     {
-        const int lenP = rowsP + 2 * (G - 1) + 4;
-        const int gstep = G % m;
-        int ph = (lig - (G - 1) - nfl) % m;
-        if (ph < 0) ph += m;
-        for (int idx = lig; idx < lenP; idx += G) {
-            const int row = idx - (G - 1);
-            int sym = kNullSym;
-            if (row >= 0 && row < rowsP) sym = row < nfl ? selb[lay.pad + row] : motifL[ph];
-            cp[idx] = (uint8_t)sym;
-            ph += gstep;
-            if (ph >= m) ph -= m;
+        if (FLY) {
+            for (int k = lig; k < 256; k += G) cp[k] = (uint8_t)(k < nfl ? selb[lay.pad + k] : kNullSym);
+        } else {
+            const int lenP = rowsP + 2 * (G - 1) + 4;
+            const int gstep = G % m;
+            int ph = (lig - (G - 1) - nfl) % m;
+            if (ph < 0) ph += m;
+            for (int idx = lig; idx < lenP; idx += G) {
+                const int row = idx - (G - 1);
+                int sym = kNullSym;
+                if (row >= 0 && row < rowsP) sym = row < nfl ? selb[lay.pad + row] : motifL[ph];
+                cp[idx] = (uint8_t)sym;
+                ph += gstep;
+                if (ph >= m) ph -= m;
+            }
         }
         const int lenT = rowsT + 2 * (G - 1) + 4;
         for (int idx = lig; idx < lenT; idx += G) {
@@ -1091,23 +1122,25 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
         }
         *w = o;
     }
-    for (int k = lig; k < (G == 8 ? kBandMaxCol8 : kBandMaxCol16); k += G) b0col[k] = (short)kBandNeg16;
+    for (int k = lig; k < lay.maxcol; k += G) b0col[k] = (short)kBandNeg16;
     wave_lds_sync();
 
     BandCtx x;
     x.lig = lig; x.first = first; x.last = last; x.tbl = tbl; x.selb = selb;
     x.pad = lay.pad; x.maxidx = lay.sel_len - 1; x.ndb = ndb;
+    x.flL = cp; x.motifL = motifL; x.nfl = nfl; x.m = m;
     const bool run = act && !fallback && geo.ok;
     const int nEff = run ? n : 0;
     // backward pass (reversed right flank x reversed window), then forward pass with the fork rows
-    band_pass<G, true>(x, ct, run ? rowsT : 0, geo.bdlo, dbEnd, cEnd, 0, 0, 1, geo.cmin, geo.ncol, comb, b0col);
+    band_pass<G, true, false>(x, ct, run ? rowsT : 0, geo.bdlo, dbEnd, cEnd, 0, 0, 1, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
-    band_pass<G, false>(x, cp, run ? rowsP : 0, geo.dlo, dbBeg, cBeg, nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col);
+    band_pass<G, false, FLY>(x, cp, run ? rowsP : 0, geo.dlo, dbBeg, cBeg, nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
     if (run) {
         for (int k = lig; k < n; k += G) {
             const int R = nfl + (lo + k) * m;
-            const int sc = max(comb[k], -(1 << 28)) - g * (R + nfr + ndb);
+            int sc = max(comb[k], -(1 << 28)) - g * (R + nfr + ndb);
+            if (FLY && cEnd) sc = max(sc, max(lmaxA[k], -(1 << 28)) - g * ndb);   // ends in the last column, in band
             comb[k] = sc;
             a.table[a.tab_off[r] + k] = sc;
         }
@@ -1145,8 +1178,15 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
     wave_lds_sync();
 }
 
-__global__ void __launch_bounds__(256) k_dp_band(KArgs a) {
-    if (a.counters[kCntClass0 + kBandClass0] + a.counters[kCntClass0 + kBandClass0 + 1] <= 0) return;
+// Two kernels so that the common short classes (0, 1) are not register-allocated together with the
+// long-window classes (2, 3).  SET 0: classes 1 then 0;  SET 1: classes 3 then 2.  Each wave pulls chunks
+// from the set's queue until it is empty.
+template <int SET>
+__device__ __forceinline__ void band_kernel_body(const KArgs& a) {
+    constexpr int CA = SET ? 3 : 1, CB = SET ? 2 : 0;   // wider class first
+    const int nA = min(a.counters[kCntClass0 + kBandClass0 + CA], a.list_stride);
+    const int nB = min(a.counters[kCntClass0 + kBandClass0 + CB], a.list_stride);
+    if (nA + nB <= 0) return;
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * kBandWaveLds + kLdsSlack];
     __shared__ uint8_t s_enc[256];
     __shared__ int8_t s_mat[kNSym * kNSym + 3];
@@ -1154,18 +1194,19 @@ __global__ void __launch_bounds__(256) k_dp_band(KArgs a) {
     for (int i = threadIdx.x; i < kNSym * kNSym; i += 256) s_mat[i] = c_mat[i / kNSym][i % kNSym];
     __syncthreads();
     uint8_t* const Lw = lds + (threadIdx.x >> 6) * kBandWaveLds;
-    const int n8 = min(a.counters[kCntClass0 + kBandClass0], a.list_stride);
-    const int n16 = min(a.counters[kCntClass0 + kBandClass0 + 1], a.list_stride);
-    const int ch16 = (n16 + 3) / 4, ch8 = (n8 + 7) / 8;
+    constexpr int perA = 64 / (8 << CA), perB = 64 / (8 << CB);   // reads per wave
+    const int chA = (nA + perA - 1) / perA, chB = (nB + perB - 1) / perB;
     for (;;) {
         int c = 0;
-        if ((threadIdx.x & 63) == 0) c = atomicAdd(&a.counters[kCntNextBand], 1);
+        if ((threadIdx.x & 63) == 0) c = atomicAdd(&a.counters[kCntNextBand + SET], 1);
         c = __builtin_amdgcn_readfirstlane(c);
-        if (c < ch16) band_wave<16>(a, c * 4, Lw, s_enc, s_mat);
-        else if (c < ch16 + ch8) band_wave<8>(a, (c - ch16) * 8, Lw, s_enc, s_mat);
+        if (c < chA) band_wave<CA>(a, c * perA, Lw, s_enc, s_mat);
+        else if (c - chA < chB) band_wave<CB>(a, (c - chA) * perB, Lw, s_enc, s_mat);
         else break;
     }
 }
+__global__ void __launch_bounds__(256) k_dp_band(KArgs a) { band_kernel_body<0>(a); }
+__global__ void __launch_bounds__(256) k_dp_band_wide(KArgs a) { band_kernel_body<1>(a); }
 
 // ---------------------------------------------------------------------------------------------
 // Long-read kernel: the same shared-prefix systolic DP for windows wider than the largest fast class

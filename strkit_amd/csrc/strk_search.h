@@ -122,48 +122,55 @@ STRK_HD SearchResult search_replay(int32_t start, int32_t step, int32_t lsr, int
 // ---------------------------------------------------------------------------------------------
 struct BandGeo {
     int32_t ok;      // eligible for the band kernel
-    int32_t G;       // lanes per read: 8 (Wd = 128) or 16 (Wd = 256); 16 diagonals per lane
-    int32_t wd;      // band width in diagonals
+    int32_t cls;     // band class 0..3: G = 8 << cls lanes per read, 16 diagonals per lane
+    int32_t G;
+    int32_t wd;      // band width in diagonals = 16 * G (128, 256, 512, 1024)
     int32_t dlo;     // forward band: d in [dlo, dlo + wd)
     int32_t bdlo;    // backward band (reversed coordinates): delta in [bdlo, bdlo + wd)
     int32_t cmin;    // first db node column the fork rows can touch
     int32_t ncol;    // number of such columns: (n - 1) * m + wd
 };
 
-constexpr int kBandMaxDb8 = 384, kBandMaxDb16 = 1024;      // |db| limits of the two band classes (LDS)
-constexpr int kBandMaxCol8 = 320, kBandMaxCol16 = 512;     // fork-column limits
+// Per-class limits (what the class's LDS layout holds).  Classes 2 and 3 generate the forward row
+// symbols on the fly (left flank <= 255 rows from LDS, then the motif with a running phase).
+constexpr int kNumBandClasses = 4;
+STRK_HD constexpr int band_class_G(int c) { return 8 << c; }
+STRK_HD constexpr int band_max_db(int c) { return c == 0 ? 384 : (c == 1 ? 1024 : (c == 2 ? 4096 : 12288)); }
+STRK_HD constexpr int band_max_col(int c) { return c == 0 ? 320 : (c == 1 ? 512 : (c == 2 ? 1024 : 1536)); }
+STRK_HD constexpr bool band_class_fly(int c) { return c >= 2; }
 constexpr int kBandMaxFlank = 127;
 constexpr int kBandRowSlack = 96;    // prefix rows a band item may have beyond |db|
 
 STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, int32_t lo, int32_t n) {
-    BandGeo b = {0, 0, 0, 0, 0, 0, 0};
+    BandGeo b = {0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t ndb = (int64_t)nfl + ntr + nfr;
     if (nfl < 1 || nfr < 1 || nfr > kBandMaxFlank || m < 1 || m > 256 || n < 1 || n > 32) return b;
     const int64_t e_lo = (int64_t)ntr - (int64_t)(lo + n - 1) * m, e_hi = (int64_t)ntr - (int64_t)lo * m;
     const int64_t span_lo = e_lo < 0 ? e_lo : 0, span_hi = e_hi > 0 ? e_hi : 0;
-    int64_t smin = ndb >> 6;
+    int64_t smin = ndb >> 6;   // slack on each side: the certificate needs ~half the score deficit of the read
     if (smin < 12) smin = 12;
     const int64_t need = span_hi - span_lo + 1 + 2 * smin;
     const int64_t rows = (int64_t)nfl + (int64_t)(lo + n - 1) * m;
-    int32_t wd = 0;
-    for (int32_t w = 128; w <= 256 && !wd; w *= 2) {   // narrowest class that holds the band and the window in LDS
+    int32_t cls = -1;
+    for (int32_t c = 0; c < kNumBandClasses && cls < 0; ++c) {   // narrowest class that holds band and window
+        const int64_t w = 128 << c;
         if (need > w) continue;
-        const int64_t ncol_w = (int64_t)(n - 1) * m + w;
-        const bool fits = w == 128 ? (ndb <= kBandMaxDb8 && ncol_w <= kBandMaxCol8 && rows <= kBandMaxDb8 + kBandRowSlack)
-                                   : (ndb <= kBandMaxDb16 && ncol_w <= kBandMaxCol16 && rows <= kBandMaxDb16 + kBandRowSlack);
-        if (fits) wd = w;
+        if (ndb > band_max_db(c) || (int64_t)(n - 1) * m + w > band_max_col(c) || rows > band_max_db(c) + kBandRowSlack) continue;
+        if (band_class_fly(c) && nfl > 255) continue;
+        cls = c;
     }
-    if (!wd) return b;
+    if (cls < 0) return b;
+    const int32_t wd = 128 << cls;
     if ((int64_t)wd * 5 > (ndb + 1) * 4) return b;   // the band must drop at least a fifth of the columns
-    const int64_t ncol = (int64_t)(n - 1) * m + wd;
     const int64_t extra = wd - (span_hi - span_lo + 1);
     b.ok = 1;
-    b.G = wd / 16;
+    b.cls = cls;
+    b.G = 8 << cls;
     b.wd = wd;
     b.dlo = (int32_t)(span_lo - extra / 2);
     b.bdlo = -(wd / 2);
     b.cmin = (int32_t)(nfl + (int64_t)lo * m + b.dlo);
-    b.ncol = (int32_t)ncol;
+    b.ncol = (int32_t)((int64_t)(n - 1) * m + wd);
     return b;
 }
 
@@ -186,7 +193,9 @@ STRK_HD int32_t band_ub(const BandGeo& b, int32_t nfl, int32_t ntr, int32_t nfr,
     if (v > L) L = v;
     v = band_len_beyond_lo(nc, ndb, e - ((int64_t)b.bdlo + b.wd - 1) - 1);
     if (v > L) L = v;
-    if (end_flags & 8) { v = band_len_beyond_hi(nc, ndb, ndb - R); if (v > L) L = v; }     // ends in the last column, row <= R_i
+    // alignments that end in the last column at a row <= R_i (free candidate end): the wide classes track
+    // the in-band ones exactly (the rest leaves the band: first term), the short classes bound them all
+    if ((end_flags & 8) && !band_class_fly(b.cls)) { v = band_len_beyond_hi(nc, ndb, ndb - R); if (v > L) L = v; }
     if (end_flags & 4) { v = band_len_beyond_lo(nc, ndb, -R - 1); if (v > L) L = v; }      // starts on the left edge below R_i
     return (int32_t)(2 * L);
 }

@@ -109,9 +109,13 @@ def test_expansion_stress_long_reads(gpu_ctx):
     """BASELINE config 5 shape (motif 1-6, hundreds of copies): windows of several kb through k_dp_long."""
     b = make_config(5, n_loci=3, reads_per_locus=4, cn_range=(700, 1100), motif_len=(3, 6))
     assert (b.nfl + b.ntr + b.nfr).max() > 1792
-    got, st = _run(b, gpu_ctx)
-    _compare(b, got, oracle_count(b))
-    assert st["n_fallback"] == 0
+    exp = oracle_count(b)
+    got, st = _run(b, gpu_ctx)                 # banded: 512 / 1 024 diagonals, rows generated on the fly
+    _compare(b, got, exp)
+    assert st["n_fallback"] == 0 and st["n_band_reads"] > 0
+    got0, st0 = _run(b, gpu_ctx, band=False)   # exact: k_dp_long
+    _compare(b, got0, exp)
+    assert st0["n_band_reads"] == 0 and st0["dp_cells"] > st["dp_cells"]
 
 
 def test_band_kernel_certifies_hifi_and_falls_back_on_noise(gpu_ctx):
