@@ -230,82 +230,102 @@ struct SeenVec {
 
 // Host-driven rounds for loci whose search left the speculative window.  Everything here works on
 // DEVICE batch pointers; host copies of the small metadata are fetched once.
+// Host copy of one locus that needs window-miss rounds: only the slices of its own reads are fetched.
+struct MissLocus {
+    int l = 0, r0 = 0, r1 = 0, m = 1;
+    int first = 0;                 // first read the host (re)plays
+    double frac = 0.0;
+    int32_t need_lo = 0, need_hi = 0;
+    std::vector<int32_t> est, win_lo, win_n, rep, nfl, ntr, nfr, table, o_cn, o_score, o_n, o_start, ext_lo;
+    std::vector<int64_t> tab_off;
+    std::vector<uint8_t> exact;
+    std::vector<std::vector<int32_t>> ext;   // exact, widened tables of re-scored reads
+};
+
 int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs a, ReplayArgs rp, hipStream_t st,
                    strk_stats* stats, int err_bits) {
-    const int nr = b->n_reads, nl = b->n_loci;
-    std::vector<int32_t> read_off(nl + 1), est(nr), win_lo(nr), win_n(nr), next_read(nl), need_lo(nl), need_hi(nl);
-    std::vector<int64_t> tab_off(nr);
+    const int nl = b->n_loci, ts = a.table_stride;
+    std::vector<int32_t> read_off(nl + 1), motif_off(nl + 1), next_read(nl), need_lo(nl), need_hi(nl);
     std::vector<double> frac(nl);
-    std::vector<int32_t> o_cn(nr), o_score(nr), o_n(nr), o_start(nr);
-    HIP_TRY(hipMemcpy(read_off.data(), b->read_off, (nl + 1) * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(est.data(), b->est_cn, (size_t)nr * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(win_lo.data(), a.win_lo, (size_t)nr * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(win_n.data(), a.win_n, (size_t)nr * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tab_off.data(), a.tab_off, (size_t)nr * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(read_off.data(), b->read_off, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(motif_off.data(), b->motif_off, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(next_read.data(), rp.next_read, (size_t)nl * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(need_lo.data(), rp.need_lo, (size_t)nl * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(need_hi.data(), rp.need_hi, (size_t)nl * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(frac.data(), rp.frac, (size_t)nl * 8, hipMemcpyDeviceToHost));
-    const size_t main_ints = (size_t)nr * a.table_stride;
-    std::vector<int32_t> table(main_ints);
-    HIP_TRY(hipMemcpy(table.data(), a.table, main_ints * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(o_cn.data(), rp.out_cn, (size_t)nr * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(o_score.data(), rp.out_score, (size_t)nr * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(o_n.data(), rp.out_n, (size_t)nr * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(o_start.data(), rp.out_start, (size_t)nr * 4, hipMemcpyDeviceToHost));
 
-    // banded tables (lower bounds + certificate) need the read geometry on the host as well
-    std::vector<uint8_t> exact_h;
-    std::vector<int32_t> rep_h, nfl_h, ntr_h, nfr_h, motif_off_h;
-    if (a.band_mode) {
-        exact_h.resize(nr); rep_h.resize(nr); nfl_h.resize(nr); ntr_h.resize(nr); nfr_h.resize(nr); motif_off_h.resize(nl + 1);
-        HIP_TRY(hipMemcpy(exact_h.data(), a.exact, (size_t)nr, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(rep_h.data(), a.rep, (size_t)nr * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(nfl_h.data(), b->nfl, (size_t)nr * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(ntr_h.data(), b->ntr, (size_t)nr * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(nfr_h.data(), b->nfr, (size_t)nr * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(motif_off_h.data(), b->motif_off, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost));
+    std::vector<MissLocus> loci;
+    for (int l = 0; l < nl; ++l) {
+        if (next_read[l] >= read_off[l + 1]) continue;
+        MissLocus L;
+        L.l = l; L.r0 = read_off[l]; L.r1 = read_off[l + 1]; L.m = motif_off[l + 1] - motif_off[l];
+        L.first = next_read[l]; L.frac = frac[l]; L.need_lo = need_lo[l]; L.need_hi = need_hi[l];
+        const size_t n = (size_t)(L.r1 - L.r0);
+        auto get32 = [&](std::vector<int32_t>& v, const int32_t* src) {
+            v.resize(n);
+            return hipMemcpy(v.data(), src + L.r0, n * 4, hipMemcpyDeviceToHost);
+        };
+        HIP_TRY(get32(L.est, b->est_cn));
+        HIP_TRY(get32(L.win_lo, a.win_lo));
+        HIP_TRY(get32(L.win_n, a.win_n));
+        HIP_TRY(get32(L.rep, a.rep));
+        HIP_TRY(get32(L.nfl, b->nfl));
+        HIP_TRY(get32(L.ntr, b->ntr));
+        HIP_TRY(get32(L.nfr, b->nfr));
+        HIP_TRY(get32(L.o_cn, rp.out_cn));
+        HIP_TRY(get32(L.o_score, rp.out_score));
+        HIP_TRY(get32(L.o_n, rp.out_n));
+        HIP_TRY(get32(L.o_start, rp.out_start));
+        L.tab_off.resize(n);
+        HIP_TRY(hipMemcpy(L.tab_off.data(), a.tab_off + L.r0, n * 8, hipMemcpyDeviceToHost));
+        L.exact.assign(n, 1);
+        if (a.band_mode) HIP_TRY(hipMemcpy(L.exact.data(), a.exact + L.r0, n, hipMemcpyDeviceToHost));
+        // copies of a read share the table slot of their first occurrence, which lies in the same locus
+        L.table.resize(n * ts);
+        HIP_TRY(hipMemcpy(L.table.data(), a.table + (size_t)L.r0 * ts, n * ts * 4, hipMemcpyDeviceToHost));
+        L.ext.resize(n);
+        L.ext_lo.assign(n, 0);
+        loci.push_back(std::move(L));
     }
-    std::vector<int> pending;  // loci
-    for (int l = 0; l < nl; ++l)
-        if (next_read[l] < read_off[l + 1]) pending.push_back(l);
-    // extended tables live on the host per read; (lo, scores)
-    std::vector<int32_t> ext_lo(nr, 0);
-    std::vector<std::vector<int32_t>> ext(nr);
-    int rounds = 0, miss_reads = 0;
-    int rc;
+
+    std::vector<MissLocus*> pending;
+    for (auto& L : loci) pending.push_back(&L);
+    int rounds = 0, miss_reads = 0, rc;
+    if ((rc = c->win_lo2.ensure((size_t)b->n_reads * 4))) return rc;
+    if ((rc = c->win_n2.ensure((size_t)b->n_reads * 4))) return rc;
+    if ((rc = c->tab_off2.ensure((size_t)b->n_reads * 8))) return rc;
     while (!pending.empty()) {
         if (++rounds > 4096) return fail(STRK_E_DEVICE, "window-miss resolution did not converge");
-        // 1. windows wanted this round
-        std::vector<int32_t> items;
-        std::vector<int32_t> w_lo(nr, 0), w_n(nr, 0);
-        std::vector<int64_t> w_off(nr, 0);
+        // 1. windows wanted this round: one read per pending locus
+        std::vector<int32_t> items, w_lo, w_n;
+        std::vector<int64_t> w_off;
         size_t tab2 = 0, n_chunks = 0;
-        for (int l : pending) {
-            const int r = next_read[l];
-            int64_t cur_lo = ext[r].empty() ? win_lo[r] : ext_lo[r];
-            int64_t cur_hi = cur_lo + (ext[r].empty() ? win_n[r] : (int64_t)ext[r].size()) - 1;
-            int64_t lo2 = std::min<int64_t>(cur_lo, std::max<int64_t>(0, (int64_t)need_lo[l] - p.window));
-            int64_t hi2 = std::max<int64_t>(cur_hi, (int64_t)need_hi[l] + p.window);
+        for (MissLocus* L : pending) {
+            const int k = L->first - L->r0;
+            const bool has_ext = !L->ext[k].empty();
+            const int64_t cur_lo = has_ext ? L->ext_lo[k] : L->win_lo[k];
+            const int64_t cur_hi = cur_lo + (has_ext ? (int64_t)L->ext[k].size() : L->win_n[k]) - 1;
+            const int64_t lo2 = std::min<int64_t>(cur_lo, std::max<int64_t>(0, (int64_t)L->need_lo - p.window));
+            const int64_t hi2 = std::max<int64_t>(cur_hi, (int64_t)L->need_hi + p.window);
             if (hi2 - lo2 + 1 > (int64_t)1 << 20) return fail(STRK_E_INVALID, "candidate window grew past 2^20 sizes");
-            w_lo[r] = (int32_t)lo2;
-            w_n[r] = (int32_t)(hi2 - lo2 + 1);
-            w_off[r] = (int64_t)tab2;
-            tab2 += (size_t)w_n[r];
-            n_chunks += ((size_t)w_n[r] + kTableMax - 1) / kTableMax;
-            items.push_back(r);
+            items.push_back(L->first);
+            w_lo.push_back((int32_t)lo2);
+            w_n.push_back((int32_t)(hi2 - lo2 + 1));
+            w_off.push_back((int64_t)tab2);
+            tab2 += (size_t)(hi2 - lo2 + 1);
+            n_chunks += ((size_t)(hi2 - lo2 + 1) + kTableMax - 1) / kTableMax;
             ++miss_reads;
         }
-        // 2. score them on the device
-        if ((rc = c->win_lo2.ensure((size_t)nr * 4))) return rc;
-        if ((rc = c->win_n2.ensure((size_t)nr * 4))) return rc;
-        if ((rc = c->tab_off2.ensure((size_t)nr * 8))) return rc;
+        // 2. score them exactly on the device (per-read window arrays are patched entry by entry)
         if ((rc = c->table2.ensure(tab2 * 4))) return rc;
         if ((rc = c->items.ensure(items.size() * 4))) return rc;
         if ((rc = c->cls_list.ensure((size_t)kNumLists * n_chunks * 2 * 4))) return rc;
-        HIP_TRY(hipMemcpyAsync(c->win_lo2.p, w_lo.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(c->win_n2.p, w_n.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(c->tab_off2.p, w_off.data(), (size_t)nr * 8, hipMemcpyHostToDevice, st));
+        for (size_t i = 0; i < items.size(); ++i) {
+            const size_t r = (size_t)items[i];
+            HIP_TRY(hipMemcpyAsync(c->win_lo2.as<int32_t>() + r, &w_lo[i], 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c->win_n2.as<int32_t>() + r, &w_n[i], 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c->tab_off2.as<int64_t>() + r, &w_off[i], 8, hipMemcpyHostToDevice, st));
+        }
         HIP_TRY(hipMemcpyAsync(c->items.p, items.data(), items.size() * 4, hipMemcpyHostToDevice, st));
         KArgs a2 = a;
         a2.win_lo = c->win_lo2.as<int32_t>();
@@ -329,74 +349,79 @@ int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs
             stats->n_fallback += c->h_counters[kCntClass0 + kGenericClass];
             stats->dp_cells += (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
         }
-        for (int r : items) {
-            ext_lo[r] = w_lo[r];
-            ext[r].assign(t2.begin() + w_off[r], t2.begin() + w_off[r] + w_n[r]);
+        for (size_t i = 0; i < pending.size(); ++i) {
+            MissLocus* L = pending[i];
+            const int k = L->first - L->r0;
+            L->ext_lo[k] = w_lo[i];
+            L->ext[k].assign(t2.begin() + w_off[i], t2.begin() + w_off[i] + w_n[i]);
         }
         // 3. replay the pending loci on the host until the next miss
-        std::vector<int> still;
-        for (int l : pending) {
-            int r = next_read[l];
-            double fr = frac[l];
+        std::vector<MissLocus*> still;
+        for (MissLocus* L : pending) {
+            int r = L->first;
+            double fr = L->frac;
             bool missed = false;
-            for (; r < read_off[l + 1]; ++r) {
-                int start = est[r];
+            for (; r < L->r1; ++r) {
+                const int k = r - L->r0;
+                int start = L->est[k];
                 double fr_try = fr;
-                if (p.feedback) start = feedback_start(est[r], &fr_try);
-                const bool use_ext = !ext[r].empty();
-                const int32_t* sc = use_ext ? ext[r].data() : table.data() + tab_off[r];
-                const int32_t lo = use_ext ? ext_lo[r] : win_lo[r];
-                const int32_t n = use_ext ? (int32_t)ext[r].size() : win_n[r];
+                if (p.feedback) start = feedback_start(L->est[k], &fr_try);
+                const bool use_ext = !L->ext[k].empty();
+                const int32_t* sc = use_ext ? L->ext[k].data() : L->table.data() + (L->tab_off[k] - (int64_t)L->r0 * ts);
+                const int32_t lo = use_ext ? L->ext_lo[k] : L->win_lo[k];
+                const int32_t n = use_ext ? (int32_t)L->ext[k].size() : L->win_n[k];
                 SeenVec seen;
                 seen.v.assign((size_t)std::max(n, 1), 0);
                 SearchResult res;
-                if (use_ext || !a.band_mode || exact_h[(size_t)rep_h[r]]) {
+                const int rpk = L->rep[k] - L->r0;   // first occurrence of this read's bytes (same locus)
+                if (use_ext || !a.band_mode || L->exact[rpk]) {
                     res = search_replay(start, p.step_size, p.local_search_range, p.max_iters, p.tie_rule == STRK_TIE_LAST, sc,
                                         lo, n, seen);
                 } else {   // banded table of the device pass: same certified search as k_replay
-                    const int rp = rep_h[r];
-                    const int m = motif_off_h[l + 1] - motif_off_h[l];
-                    const BandGeo geo = band_geometry(nfl_h[rp], ntr_h[rp], nfr_h[rp], m, lo, n);
-                    auto ub = [&](int k) { return band_ub(geo, nfl_h[rp], ntr_h[rp], nfr_h[rp], m, lo + k, p.end_flags); };
+                    const BandGeo geo = band_geometry(L->nfl[rpk], L->ntr[rpk], L->nfr[rpk], L->m, lo, n);
+                    auto ub = [&](int kk) { return band_ub(geo, L->nfl[rpk], L->ntr[rpk], L->nfr[rpk], L->m, lo + kk, p.end_flags); };
                     const CertResult cr = search_replay_cert(start, p.step_size, p.local_search_range, p.max_iters,
                                                              p.tie_rule == STRK_TIE_LAST, sc, lo, n, seen, ub);
                     res = cr.res;
                     if (cr.uncertain) { res.miss = 1; res.need_lo = lo; res.need_hi = lo + n - 1; }
                 }
                 if (res.miss) {
-                    need_lo[l] = res.need_lo;
-                    need_hi[l] = res.need_hi;
+                    L->need_lo = res.need_lo;
+                    L->need_hi = res.need_hi;
                     missed = true;
                     break;
                 }
                 fr = fr_try;
-                o_start[r] = start;
-                o_n[r] = res.n_explored;
+                L->o_start[k] = start;
+                L->o_n[k] = res.n_explored;
                 if (res.empty) {
-                    o_cn[r] = 0; o_score[r] = 0;
-                    c->h_counters[kCntError] |= kErrEmpty;
+                    L->o_cn[k] = 0; L->o_score[k] = 0;
+                    err_bits |= kErrEmpty;
                     continue;
                 }
-                o_cn[r] = res.cn;
-                o_score[r] = res.score;
+                L->o_cn[k] = res.cn;
+                L->o_score[k] = res.score;
                 if (p.feedback) feedback_update(&fr, res.cn, start);
             }
-            next_read[l] = r;
-            frac[l] = fr;
-            if (missed) still.push_back(l);
+            L->first = r;
+            L->frac = fr;
+            if (missed) still.push_back(L);
         }
         pending.swap(still);
     }
-    HIP_TRY(hipMemcpyAsync(rp.out_cn, o_cn.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(rp.out_score, o_score.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(rp.out_n, o_n.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(rp.out_start, o_start.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+    for (auto& L : loci) {   // write back the reads the host finished
+        const size_t n = (size_t)(L.r1 - L.r0);
+        HIP_TRY(hipMemcpyAsync(rp.out_cn + L.r0, L.o_cn.data(), n * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(rp.out_score + L.r0, L.o_score.data(), n * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(rp.out_n + L.r0, L.o_n.data(), n * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(rp.out_start + L.r0, L.o_start.data(), n * 4, hipMemcpyHostToDevice, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     if (stats) {
         stats->n_miss_reads = miss_reads;
         stats->n_miss_rounds = rounds;
     }
-    return check_error_bits(c->h_counters[kCntError] | err_bits);
+    return check_error_bits(err_bits);
 }
 
 // Enqueue one batched call on `st` and return without waiting.
