@@ -17,6 +17,8 @@
  *   strk_ref_repeat_count    get_ref_repeat_count() incl. score_ref_boundaries(), once per locus
  *                            — strkit/call/repeats.py:23-43,73-192 (parasail sg_qe_scan_profile_sat);
  *                            strk_score_ref_table is its scoring primitive
+ *   strk_realign             the parasail sg_dx_trace_scan_16 call + CIGAR of realign_read()
+ *                            — strkit/call/realign.py:56-72 (gate at realign.py:65, caller call_locus.py:867-901)
  *   strk_score_table         one parasail semi-global alignment score per candidate copy number
  *                            (the innermost operation; shape of strkit/call/repeats.py:33,40,124)
  *
@@ -171,6 +173,21 @@ int strk_ref_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr,
                           const uint8_t* motif, int32_t motif_len, int32_t ref_size,
                           int32_t vcf_anchor_size, int32_t max_iters, int32_t local_search_range,
                           int32_t step_size, int32_t respect_coords, int32_t* out9);
+
+/* Batched drop-in for the parasail call of realign_read (strkit/call/realign.py:56-63,71):
+ * sg_dx_trace_scan_16(s1 = reference window, s2 = wildcarded read, open, extend, dna_matrix) — s1 aligned end
+ * to end, both ends of s2 free, a gap of length k costs open + (k-1)*extend (the reference passes 7 and 0).
+ * Pair p owns s1[s1_off[p] .. s1_off[p+1]) and s2[s2_off[p] .. s2_off[p+1]); HOST buffers.
+ * Outputs per pair: out_score = pr.score; out_end_ref = 0-based s2 position of the last aligned base
+ * (pr.end_ref); the CIGAR of pr.cigar.seq in BAM encoding (len << 4 | op, ops "MIDNSHP=X": I consumes s1,
+ * D consumes s2), written to cigar[cigar_off[p] ..] with out_n_cigar[p] runs; it starts at s2 position 0
+ * (free leading s2 bases are one D run) and ends at out_end_ref.  2*|s1| + 4 runs always suffice.
+ * gap_pref: which gap kind wins an exact score tie after the diagonal (0: I before D, the default; 1: D before I).
+ * stats (optional): kernel_ms, dp_cells, exact_bytes = trace bytes written. */
+int strk_realign(strk_ctx* ctx, int32_t n_pairs, const uint8_t* s1, const int64_t* s1_off, const uint8_t* s2,
+                 const int64_t* s2_off, int32_t open, int32_t extend, int32_t gap_pref, int32_t* out_score,
+                 int32_t* out_end_ref, int32_t* out_n_cigar, uint32_t* cigar, const int64_t* cigar_off,
+                 strk_stats* stats);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,9 @@ def lib():
         L.strk_o_score_ref_boundaries.restype = None
         L.strk_o_score_ref_boundaries.argtypes = [_u8p, C.c_int32] * 4 + [C.c_int32, C.c_int32, _i32p]
         L.strk_o_ref_repeat_count.restype = C.c_int
+        L.strk_o_realign.argtypes = [_u8p, C.c_int32, _u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p,
+                                     C.POINTER(C.c_uint32), C.c_int32]
+        L.strk_o_realign.restype = C.c_int32
         L.strk_o_ref_repeat_count.argtypes = ([C.c_int32] + [_u8p, C.c_int32] * 4 + [C.c_int32] * 8 + [_i32p])
         L.strk_o_init()
         _lib = L
@@ -155,3 +158,15 @@ def ref_repeat_count(start_count: int, tr: str, fl: str, fr: str, motif: str, re
     nfl2, ntr2, nfr2 = o[6], o[7], o[8]
     return ((o[0], o[1]), o[2], o[3], (o[4], o[5]),
             (db[:nfl2], db[nfl2:nfl2 + ntr2], db[nfl2 + ntr2:nfl2 + ntr2 + nfr2]))
+
+
+def realign(s1, s2, open_: int = 7, ext: int = 0, gap_pref: int = 0):
+    """parasail sg_dx_trace (realign.py:56-63): (score, end position in s2, CIGAR runs as BAM uint32)."""
+    b1, n1 = _b(s1); b2, n2 = _b(s2)
+    cap = 2 * n1 + 4
+    cig = (C.c_uint32 * cap)()
+    sc, e2 = C.c_int32(), C.c_int32()
+    n = lib().strk_o_realign(b1, n1, b2, n2, open_, ext, gap_pref, C.byref(sc), C.byref(e2), cig, cap)
+    if n < 0:
+        raise ValueError("realign: empty input" if n == -2 else "realign: CIGAR capacity")
+    return sc.value, e2.value, np.frombuffer(cig, dtype=np.uint32, count=n).copy()

@@ -509,3 +509,110 @@ int strk_o_ref_repeat_count(int32_t start_count, const uint8_t* tr, int32_t ntr,
     free(db);
     return rc;
 }
+
+/* ---- realignment (strkit/call/realign.py:56-72) ------------------------------------------
+ * parasail sg_dx_trace_scan_16(s1 = reference window, s2 = wildcarded read, open = 7, extend = 0,
+ * dna_matrix): s1 is aligned end to end, leading and trailing s2 bases are free.  Gap of length
+ * k costs open + (k-1)*extend (so with extend = 0 every gap costs 7).  The recurrence is the one
+ * of strk_o_sg_align; this function also keeps the trace-back tables and emits the CIGAR the
+ * reference reads as pr.cigar.seq (BAM encoding len<<4|op, ops from "MIDNSHP=X": I = 1 consumes
+ * s1 only, D = 2 consumes s2 only, '=' = 7, 'X' = 8), s1 as "query", s2 as "ref".
+ *
+ * Choices parasail leaves to its implementation (its source is not under /root/reference — the
+ * rules below restate its trace kernels from memory and are named so they can be flipped):
+ *   - H tie:   diagonal first, then (gap_pref == 0) the gap that consumes s1 ('I'), then the gap
+ *              that consumes s2 ('D');  gap_pref == 1 swaps the two gap kinds
+ *   - gap tie: extension wins over opening (open only when strictly greater)
+ *   - end:     smallest s2 end position among the maxima of the last row
+ *   - '='/'X': '=' when both bases encode to the same alphabet letter (case-insensitive)
+ * The CIGAR starts at s2 position 0: the free leading s2 bases appear as one D run (the
+ * reference passes ref_start = 0 to get_aligned_pair_matches, realign.py:71); trailing free s2
+ * bases are not part of it.  The 16-bit saturating arithmetic of the _16 kernel is not modelled:
+ * scores here are exact int32 (they fit int16 whenever 2*n1 < 32 767).
+ *
+ * Returns the number of CIGAR runs written (<= cap), or -1 if cap is too small, -2 on empty input.
+ */
+#define TB_H_DIAG 2
+#define TB_H_GI 1 /* gap consuming s1: 'I' */
+#define TB_H_GD 0 /* gap consuming s2: 'D' */
+#define TB_GI_EXT 4
+#define TB_GD_EXT 8
+
+int32_t strk_o_realign(const uint8_t* s1, int32_t n1, const uint8_t* s2, int32_t n2, int32_t open,
+                       int32_t ext, int32_t gap_pref, int32_t* out_score, int32_t* out_end2,
+                       uint32_t* cigar, int32_t cap) {
+    strk_o_init();
+    if (n1 <= 0 || n2 <= 0) return -2;
+    const int32_t NEG = INT32_MIN / 4;
+    const size_t W = (size_t)n2 + 1;
+    int32_t* H = (int32_t*)malloc(sizeof(int32_t) * W);
+    int32_t* GI = (int32_t*)malloc(sizeof(int32_t) * W);           /* per column j, runs along i */
+    uint8_t* T = (uint8_t*)malloc((size_t)(n1 + 1) * W);
+    H[0] = 0;
+    for (int32_t j = 1; j <= n2; j++) { H[j] = 0; GI[j] = NEG; }
+    for (int32_t i = 1; i <= n1; i++) {
+        const int8_t* wrow = g_mat[g_enc[s1[i - 1]]];
+        uint8_t* trow = T + (size_t)i * W;
+        int32_t diag = H[0];
+        H[0] = -(open + (i - 1) * ext);
+        int32_t GD = NEG;                                           /* runs along j */
+        for (int32_t j = 1; j <= n2; j++) {
+            uint8_t t = 0;
+            int32_t d_ext = GD - ext, d_opn = H[j - 1] - open;
+            if (d_opn > d_ext) GD = d_opn; else { GD = d_ext; t |= TB_GD_EXT; }
+            int32_t i_ext = GI[j] - ext, i_opn = H[j] - open;
+            if (i_opn > i_ext) GI[j] = i_opn; else { GI[j] = i_ext; t |= TB_GI_EXT; }
+            int32_t h = diag + wrow[g_enc[s2[j - 1]]];
+            int32_t first = gap_pref ? GD : GI[j], second = gap_pref ? GI[j] : GD;
+            uint8_t tf = gap_pref ? TB_H_GD : TB_H_GI, ts = gap_pref ? TB_H_GI : TB_H_GD;
+            uint8_t th = TB_H_DIAG;
+            if (first > h) { h = first; th = tf; }
+            if (second > h) { h = second; th = ts; }
+            diag = H[j];
+            H[j] = h;
+            trow[j] = (uint8_t)(t | th);
+        }
+    }
+    int32_t best = H[1], bj = 1;
+    for (int32_t j = 2; j <= n2; j++)
+        if (H[j] > best) { best = H[j]; bj = j; }
+    if (out_score) *out_score = best;
+    if (out_end2) *out_end2 = bj - 1;
+    /* trace-back, runs collected in reverse */
+    int32_t n = 0, rc = 0;
+    uint32_t* rev = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(2 * n1 + 4));
+    int32_t i = n1, j = bj, where = TB_H_DIAG;
+#define PUSH(op)                                                          \
+    do {                                                                  \
+        if (n > 0 && (rev[n - 1] & 15u) == (uint32_t)(op)) rev[n - 1] += 16u; \
+        else rev[n++] = 16u | (uint32_t)(op);                             \
+    } while (0)
+    while (i > 0 || j > 0) {
+        if (i == 0) { PUSH(2); j--; continue; }
+        if (j == 0) { PUSH(1); i--; continue; }
+        const uint8_t t = T[(size_t)i * W + j];
+        if (where == TB_H_DIAG) {
+            const int th = t & 3;
+            if (th == TB_H_DIAG) {
+                PUSH(g_enc[s1[i - 1]] == g_enc[s2[j - 1]] ? 7 : 8);
+                i--; j--;
+            } else where = th;
+        } else if (where == TB_H_GI) {
+            PUSH(1);
+            if (!(t & TB_GI_EXT)) where = TB_H_DIAG;
+            i--;
+        } else {
+            PUSH(2);
+            if (!(t & TB_GD_EXT)) where = TB_H_DIAG;
+            j--;
+        }
+    }
+#undef PUSH
+    if (n > cap) rc = -1;
+    else {
+        for (int32_t k = 0; k < n; k++) cigar[k] = rev[n - 1 - k];
+        rc = n;
+    }
+    free(rev); free(T); free(GI); free(H);
+    return rc;
+}

@@ -10,15 +10,18 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/strkit_amd.h"
 #include "strk_kernels.h"
+#include "strk_realign.h"
 
 extern "C" int strk_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int32_t tr_len, const uint8_t* fl,
                                  int32_t fl_len, const uint8_t* fr, int32_t fr_len, const uint8_t* motif, int32_t motif_len,
@@ -85,6 +88,8 @@ struct strk_ctx {
     // staging for the host-buffer entry points
     DevBuf in_seqs, in_seq_off, in_nfl, in_ntr, in_nfr, in_est, in_read_off, in_motifs, in_motif_off;
     DevBuf out_cn, out_score, out_n, out_start;
+    // realignment (strk_realign)
+    DevBuf rl_s1, rl_s2, rl_pairs, rl_trace, rl_edge, rl_out, rl_cigar, rl_queue;
     int32_t* h_counters = nullptr;  // pinned: counters + cells + scratch_used
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // call start, exact DP start/end, call end, band start/end
     size_t scratch_ints = 0;
@@ -775,6 +780,191 @@ int ref_repeat_count_impl(strk_ctx* ctx, int32_t start_count, const uint8_t* tr,
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Realignment: strk_realign (strkit/call/realign.py:56-72)
+// ---------------------------------------------------------------------------------------------
+// Launches the DP kernel of one column class on pairs [first, first + count) of a.pairs (persistent grid).
+template <int CL, bool EXT0>
+void launch_realign_dp_t(const RealignArgs& a, int first, int count, int qslot, int device) {
+    static int resident = 0;   // blocks that fit the device (queried once per instantiation)
+    if (resident == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_realign_dp<CL, EXT0>, 256, 0) != hipSuccess) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
+        resident = std::max(1, per_cu) * std::max(1, cus);
+    }
+    const int blocks = std::min(resident, (count + 3) / 4);
+    hipLaunchKernelGGL((k_realign_dp<CL, EXT0>), dim3(blocks), dim3(256), 0, nullptr, a, first, count, qslot);
+}
+void launch_realign_dp(int cl, bool ext0, const RealignArgs& a, int first, int count, int qslot, int device) {
+    switch (cl) {
+        case 4: ext0 ? launch_realign_dp_t<4, true>(a, first, count, qslot, device) : launch_realign_dp_t<4, false>(a, first, count, qslot, device); break;
+        case 8: ext0 ? launch_realign_dp_t<8, true>(a, first, count, qslot, device) : launch_realign_dp_t<8, false>(a, first, count, qslot, device); break;
+        case 16: ext0 ? launch_realign_dp_t<16, true>(a, first, count, qslot, device) : launch_realign_dp_t<16, false>(a, first, count, qslot, device); break;
+        default: ext0 ? launch_realign_dp_t<32, true>(a, first, count, qslot, device) : launch_realign_dp_t<32, false>(a, first, count, qslot, device); break;
+    }
+}
+
+int realign_impl(strk_ctx* c, int32_t n_pairs, const uint8_t* s1, const int64_t* s1_off, const uint8_t* s2,
+                 const int64_t* s2_off, int32_t open, int32_t ext, int32_t gap_pref, int32_t* out_score,
+                 int32_t* out_end_ref, int32_t* out_n_cigar, uint32_t* cigar, const int64_t* cigar_off, strk_stats* stats) {
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (n_pairs < 0) return fail(STRK_E_INVALID, "n_pairs < 0");
+    if (n_pairs == 0) return 0;
+    if (!s1 || !s1_off || !s2 || !s2_off || !out_score || !out_end_ref || !out_n_cigar || !cigar || !cigar_off)
+        return fail(STRK_E_INVALID, "NULL argument");
+    if (open < 0 || ext < 0 || open > 4096 || ext > open) return fail(STRK_E_INVALID, "need 0 <= extend <= open <= 4096");
+    if (gap_pref != 0 && gap_pref != 1) return fail(STRK_E_INVALID, "bad gap_pref");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t trace_budget = (size_t)16 << 30;
+    if (const char* e = getenv("STRKIT_AMD_TRACE_BYTES")) trace_budget = std::max<size_t>((size_t)strtoull(e, nullptr, 10), 1 << 20);
+
+    std::vector<RealignPair> all((size_t)n_pairs);
+    std::vector<size_t> trace_bytes((size_t)n_pairs);
+    for (int p = 0; p < n_pairs; ++p) {
+        const int64_t n1 = s1_off[p + 1] - s1_off[p], n2 = s2_off[p + 1] - s2_off[p], cap = cigar_off[p + 1] - cigar_off[p];
+        if (n1 < 1 || n2 < 1) return fail(STRK_E_INVALID, "pair %d: empty sequence", p);
+        if (n1 > (1 << 20) || n2 > (1 << 24)) return fail(STRK_E_INVALID, "pair %d: sequence too long (%lld x %lld)", p, (long long)n1, (long long)n2);
+        if (cap < 0) return fail(STRK_E_INVALID, "pair %d: negative CIGAR capacity", p);
+        RealignPair& r = all[p];
+        r.s1_off = s1_off[p] - s1_off[0];
+        r.s2_off = s2_off[p] - s2_off[0];
+        r.n1 = (int32_t)n1;
+        r.n2 = (int32_t)n2;
+        r.cl = n1 <= 256 ? 4 : n1 <= 512 ? 8 : n1 <= 1024 ? 16 : 32;
+        r.ntiles = (int32_t)((n1 + 64 * r.cl - 1) / (64 * r.cl));
+        r.pad = r.ntiles * 64 * r.cl - (int32_t)n1;
+        r.cig_cap = (int32_t)std::min<int64_t>(cap, 2 * n1 + 4);
+        r.orig = p;
+        r.reserved = 0;
+        const size_t tb = (size_t)r.ntiles * (size_t)(n2 + 63) * 64 * (size_t)(r.cl / 2);
+        trace_bytes[p] = (tb + 255) & ~(size_t)255;
+        if (trace_bytes[p] > ((size_t)128 << 30)) return fail(STRK_E_NOMEM, "pair %d: trace of %zu bytes", p, trace_bytes[p]);
+    }
+    int rc;
+    const size_t s1_bytes = (size_t)(s1_off[n_pairs] - s1_off[0]), s2_bytes = (size_t)(s2_off[n_pairs] - s2_off[0]);
+    if ((rc = c->rl_s1.ensure(s1_bytes + 16))) return rc;
+    if ((rc = c->rl_s2.ensure(s2_bytes + 16))) return rc;
+    if ((rc = c->rl_queue.ensure(64))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->rl_s1.p, s1 + s1_off[0], s1_bytes, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(c->rl_s2.p, s2 + s2_off[0], s2_bytes, hipMemcpyHostToDevice, nullptr));
+
+    hipEvent_t ev0 = c->ev[0], ev1 = c->ev[3];
+    for (int p0 = 0; p0 < n_pairs;) {
+        // one chunk: as many pairs (caller order) as fit the trace budget
+        int p1 = p0;
+        size_t tsum = 0, esum = 0, csum = 0;
+        while (p1 < n_pairs && (p1 == p0 || tsum + trace_bytes[p1] <= trace_budget)) {
+            tsum += trace_bytes[p1];
+            if (all[p1].ntiles > 1) esum += (size_t)4 * all[p1].n2;
+            csum += (size_t)all[p1].cig_cap;
+            ++p1;
+        }
+        const int n = p1 - p0;
+        std::vector<RealignPair> chunk(all.begin() + p0, all.begin() + p1);
+        std::stable_sort(chunk.begin(), chunk.end(), [](const RealignPair& x, const RealignPair& y) {   // widest class first, then most work first
+            if (x.cl != y.cl) return x.cl > y.cl;
+            return (int64_t)x.ntiles * (x.n2 + 63) > (int64_t)y.ntiles * (y.n2 + 63);
+        });
+        size_t toff = 0, eoff = 0, coff = 0;
+        for (auto& r : chunk) {
+            r.trace_off = (int64_t)toff;
+            toff += trace_bytes[r.orig];
+            r.edge_off = r.ntiles > 1 ? (int64_t)eoff : -1;
+            if (r.ntiles > 1) eoff += (size_t)4 * r.n2;
+            r.cig_off = (int64_t)coff;
+            coff += (size_t)r.cig_cap;
+            r.orig -= p0;
+        }
+        if ((rc = c->rl_pairs.ensure((size_t)n * sizeof(RealignPair)))) return rc;
+        if ((rc = c->rl_trace.ensure(tsum + 256))) return rc;
+        if ((rc = c->rl_edge.ensure(std::max<size_t>(esum, 1) * 4))) return rc;
+        if ((rc = c->rl_out.ensure((size_t)n * 3 * 4))) return rc;
+        if ((rc = c->rl_cigar.ensure(std::max<size_t>(csum, 1) * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->rl_pairs.p, chunk.data(), (size_t)n * sizeof(RealignPair), hipMemcpyHostToDevice, nullptr));
+        HIP_TRY(hipMemsetAsync(c->rl_queue.p, 0, 64, nullptr));
+        RealignArgs a{};
+        a.pairs = c->rl_pairs.as<RealignPair>();
+        a.n_pairs = n;
+        a.open = open;
+        a.ext = ext;
+        a.gap_pref = gap_pref;
+        a.s1 = c->rl_s1.as<uint8_t>();
+        a.s2 = c->rl_s2.as<uint8_t>();
+        a.trace = c->rl_trace.as<uint8_t>();
+        a.edge = c->rl_edge.as<int32_t>();
+        a.score = c->rl_out.as<int32_t>();
+        a.end2 = a.score + n;
+        a.n_cigar = a.score + 2 * n;
+        a.cigar = c->rl_cigar.as<uint32_t>();
+        a.queue = c->rl_queue.as<int32_t>();
+        a.cells = reinterpret_cast<unsigned long long*>(c->rl_queue.as<char>() + 32);
+        HIP_TRY(hipEventRecord(ev0, nullptr));
+        int32_t* hdbg = nullptr;
+        const bool dbg = getenv("STRKIT_AMD_RL_DEBUG") != nullptr;
+        if (dbg) {   // progress markers per wave of block 0, host-visible (diagnosis of a kernel that does not finish)
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hdbg), 4096, hipHostMallocMapped));
+            memset(hdbg, 0, 4096);
+            a.dbg = hdbg;
+        }
+        for (int first = 0, q = 0; first < n; ++q) {
+            int cnt = 1;
+            while (first + cnt < n && chunk[first + cnt].cl == chunk[first].cl) ++cnt;
+            launch_realign_dp(chunk[first].cl, ext == 0, a, first, cnt, q, c->device);
+            first += cnt;
+        }
+        hipLaunchKernelGGL(k_realign_trace, dim3((n + 63) / 64), dim3(64), 0, nullptr, a);
+        HIP_TRY(hipEventRecord(ev1, nullptr));
+        std::vector<int32_t> o((size_t)n * 3);
+        std::vector<uint32_t> cg(std::max<size_t>(csum, 1));
+        unsigned long long cells = 0;
+        HIP_TRY(hipMemcpyAsync(o.data(), c->rl_out.p, (size_t)n * 3 * 4, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipMemcpyAsync(cg.data(), c->rl_cigar.p, csum * 4, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipMemcpyAsync(&cells, c->rl_queue.as<char>() + 32, 8, hipMemcpyDeviceToHost, nullptr));
+        {   // watchdog: the chunk's cells at a pessimistic 1 GCUPS, plus a minute
+            double work = 0;
+            for (const auto& r : chunk) work += (double)r.ntiles * 64 * r.cl * (r.n2 + 63);
+            const double limit_s = 60.0 + work / 1e9;
+            const auto t0 = std::chrono::steady_clock::now();
+            hipError_t q;
+            while ((q = hipStreamQuery(nullptr)) == hipErrorNotReady) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+                    if (hdbg)
+                        for (int w = 0; w < 4; ++w)
+                            fprintf(stderr, "[strk_realign] wave %d: iters=%d item=%d cl=%d n2=%d t=%d done=%d\n", w, hdbg[w * 8],
+                                    hdbg[w * 8 + 1], hdbg[w * 8 + 2], hdbg[w * 8 + 3], hdbg[w * 8 + 4], hdbg[w * 8 + 5]);
+                    return fail(STRK_E_DEVICE, "realignment kernels did not finish within %.0f s", limit_s);
+                }
+                usleep(50);
+            }
+            if (q != hipSuccess) return fail(STRK_E_DEVICE, "realignment kernels: %s", hipGetErrorString(q));
+        }
+        if (hdbg) (void)hipHostFree(hdbg);
+        HIP_TRY(hipGetLastError());
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        if (stats) {
+            stats->kernel_ms += ms;
+            stats->dp_kernel_ms += ms;
+            stats->dp_cells += (int64_t)cells;
+            stats->n_dp_launches += 1;
+            stats->exact_bytes += (int64_t)tsum;   // trace bytes written (the kernel's real HBM traffic)
+        }
+        for (const auto& r : chunk) {
+            const int p = r.orig + p0;
+            out_score[p] = o[r.orig];
+            out_end_ref[p] = o[(size_t)n + r.orig];
+            const int32_t nc = o[(size_t)2 * n + r.orig];
+            if (nc < 0) return fail(STRK_E_INVALID, "pair %d: CIGAR capacity %d too small", p, r.cig_cap);
+            out_n_cigar[p] = nc;
+            memcpy(cigar + cigar_off[p], cg.data() + r.cig_off, (size_t)nc * 4);
+        }
+        p0 = p1;
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -816,7 +1006,8 @@ void strk_destroy(strk_ctx* c) {
                       &c->scratch, &c->state_i32, &c->state_f64, &c->spec, &c->rhash, &c->rep, &c->exact, &c->win_lo2, &c->win_n2, &c->tab_off2, &c->table2,
                       &c->items, &c->in_seqs, &c->in_seq_off, &c->in_nfl, &c->in_ntr, &c->in_nfr, &c->in_est,
                       &c->in_read_off, &c->in_motifs, &c->in_motif_off, &c->out_cn, &c->out_score, &c->out_n,
-                      &c->out_start};
+                      &c->out_start, &c->rl_s1, &c->rl_s2, &c->rl_pairs, &c->rl_trace, &c->rl_edge, &c->rl_out, &c->rl_cigar,
+                      &c->rl_queue};
     for (DevBuf* b : bufs) b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (auto& e : c->ev)
@@ -921,6 +1112,15 @@ int strk_ref_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr,
     if (local_search_range < 0 || step_size < 1) return fail(STRK_E_INVALID, "local_search_range must be >= 0 and step_size >= 1");
     return ref_repeat_count_impl(ctx, start_count, tr, tr_len, fl, fl_len, fr, fr_len, motif, motif_len, ref_size,
                                  vcf_anchor_size, max_iters, local_search_range, step_size, respect_coords, out9);
+}
+
+int strk_realign(strk_ctx* ctx, int32_t n_pairs, const uint8_t* s1, const int64_t* s1_off, const uint8_t* s2,
+                 const int64_t* s2_off, int32_t open, int32_t extend, int32_t gap_pref, int32_t* out_score,
+                 int32_t* out_end_ref, int32_t* out_n_cigar, uint32_t* cigar, const int64_t* cigar_off, strk_stats* stats) {
+    if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
+    if (ctx->pending) return fail(STRK_E_INVALID, "a submitted call is pending on this context");
+    return realign_impl(ctx, n_pairs, s1, s1_off, s2, s2_off, open, extend, gap_pref, out_score, out_end_ref, out_n_cigar,
+                        cigar, cigar_off, stats);
 }
 
 }  // extern "C"

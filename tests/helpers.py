@@ -69,3 +69,62 @@ def oracle_count(b: LocusBatch, max_iters=50, lsr=3, step=1, tie_rule=0, flags=1
         for k in res:
             res[k][r0:r1] = o[k]
     return res
+
+
+# ---- realignment (strkit/call/realign.py) ---------------------------------------------------
+def mutate(rng, seq, sub=0.01, indel=0.01, alpha=ALPHA_ACGT):
+    out = []
+    for ch in seq:
+        x = rng.random()
+        if x < sub:
+            out.append(alpha[rng.integers(len(alpha))])
+        elif x < sub + indel / 2:
+            continue
+        elif x < sub + indel:
+            out.append(ch)
+            out.append(alpha[rng.integers(len(alpha))])
+        else:
+            out.append(ch)
+    return "".join(out)
+
+
+def realign_pair(rng, n_ref, n_read, ins=0, dele=0, sub=0.01, indel=0.01, alpha=ALPHA_ACGT, wc=0.0):
+    """A reference window of n_ref bases and a read of about n_read bases that contains a mutated copy of it
+    (optionally with one large insertion / deletion in the middle, the soft-clip case of call_locus.py:860-865)."""
+    ref = rand_seq(rng, n_ref, alpha)
+    mid = n_ref // 2
+    body = ref[:mid] + rand_seq(rng, ins, alpha) + ref[mid + dele:]
+    body = mutate(rng, body, sub, indel, alpha)
+    left = int(rng.integers(0, max(1, n_read - len(body)) + 1)) if n_read > len(body) else 0
+    right = max(0, n_read - len(body) - left)
+    read = rand_seq(rng, left, alpha) + body + rand_seq(rng, right, alpha)
+    if wc > 0:
+        read = "".join("X" if rng.random() < wc else ch for ch in read)
+    return ref, read or "A"
+
+
+def cigar_tuples(cig):
+    return [(int(x) >> 4, "MIDNSHP=X"[int(x) & 15]) for x in cig]
+
+
+def rescore_cigar(ref, read, cig, open_=7, ext=0):
+    """Score of the alignment a CIGAR describes (s1 = ref window, s2 = read; leading D run is free)."""
+    M = oracle.matrix()
+    i = j = 0
+    score = 0
+    first = True
+    for ln, op in cigar_tuples(cig):
+        if op in "=X":
+            for _ in range(ln):
+                score += int(M[oracle.encode(ref[i]), oracle.encode(read[j])])
+                i += 1
+                j += 1
+        elif op == "I":
+            score -= open_ + (ln - 1) * ext
+            i += ln
+        elif op == "D":
+            if not (first and i == 0):
+                score -= open_ + (ln - 1) * ext
+            j += ln
+        first = False
+    return score, i, j

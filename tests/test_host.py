@@ -141,3 +141,15 @@ def test_two_rank_gather_equals_single_process():
     for rank in (0, 1):
         for k, v in exp.items():
             assert got[rank][k] == v.tolist()
+
+
+def test_aligned_pair_matches_from_cigar():
+    from strkit_amd.realign import cigar_to_string, get_aligned_pair_matches
+    enc = {"M": 0, "I": 1, "D": 2, "=": 7, "X": 8}
+    cig = np.array([(n << 4) | enc[o] for n, o in [(3, "D"), (2, "="), (1, "I"), (1, "X"), (2, "D"), (2, "=")]], np.uint32)
+    assert cigar_to_string(cig) == "3D2=1I1X2D2="
+    ac = get_aligned_pair_matches(cig, 100, 0, swap=True)      # "query" = ref window at 100, "ref" = read at 0
+    assert ac.ref_coords.tolist() == [100, 101, 103, 104, 105]
+    assert ac.query_coords.tolist() == [3, 4, 5, 8, 9]
+    ac2 = get_aligned_pair_matches(cig, 100, 0)
+    assert ac2.query_coords.tolist() == ac.ref_coords.tolist() and len(ac2) == 5 and ac2.pair_at_idx(2) == (103, 5)

@@ -167,3 +167,57 @@ def test_golden_score_tables():
     for flags, tabs in g["tables"].items():
         got = oracle_table(b, g["lo"], g["n"], int(flags))
         assert [t.tolist() for t in got] == tabs, flags
+
+
+# ---- realignment restatement (strkit/call/realign.py:56-72) -----------------------------------
+def _py_sg_dx_score(s1, s2, open_, ext):
+    """Independent three-state Gotoh in pure Python: s1 global, both ends of s2 free."""
+    M = oracle.matrix()
+    NEG = -10**9
+    n2 = len(s2)
+    H = [0] * (n2 + 1)
+    GI = [NEG] * (n2 + 1)
+    for i in range(1, len(s1) + 1):
+        a = oracle.encode(s1[i - 1])
+        diag, H[0], GD = H[0], -(open_ + (i - 1) * ext), NEG
+        for j in range(1, n2 + 1):
+            GD = max(GD - ext, H[j - 1] - open_)
+            GI[j] = max(GI[j] - ext, H[j] - open_)
+            h = max(diag + int(M[a, oracle.encode(s2[j - 1])]), GI[j], GD)
+            diag, H[j] = H[j], h
+    return max(H[1:])
+
+
+def test_realign_known_answers():
+    from helpers import cigar_tuples
+    sc, e2, cg = oracle.realign("ACGTACGTAC", "TTTTACGTACGTACTTT")
+    assert (sc, e2, cigar_tuples(cg)) == (20, 13, [(4, "D"), (10, "=")])
+    # a 4-base insertion in the window costs one gap of 7 (extend 0): 2*10 - 7
+    sc, e2, cg = oracle.realign("ACGTACGGGGGTAC", "TTTTACGTACGTACTTT")
+    assert (sc, cigar_tuples(cg)) == (13, [(4, "D"), (6, "="), (4, "I"), (4, "=")])
+    # a 24-base expansion in the read costs the same 7
+    sc, e2, cg = oracle.realign("ACGTACGTAC", "TTTTACGTAAAAAAAAAAAAAAAAAAAAAAAAACGTACTTT")
+    assert (sc, e2, cigar_tuples(cg)) == (13, 37, [(4, "D"), (4, "="), (24, "D"), (6, "=")])
+    # X scores 0, a mismatch -7 ('X' op in both cases: the letters differ)
+    sc, _, cg = oracle.realign("ACGT", "AXGT")
+    assert (sc, cigar_tuples(cg)) == (6, [(1, "="), (1, "X"), (2, "=")])
+    # score agrees with the end-gap-flag scorer used by the counting path
+    assert oracle.sg_align("ACGTTGCA", "GGACGTGCAGG", 7, 0, oracle.S2_BEG_FREE | oracle.S2_END_FREE)[0] == \
+        oracle.realign("ACGTTGCA", "GGACGTGCAGG")[0]
+
+
+def test_realign_matches_python_restatement_and_its_own_cigar():
+    from helpers import ALPHA_WC, rand_seq, realign_pair, rescore_cigar
+    rng = np.random.default_rng(31)
+    for k in range(40):
+        open_, ext = [(7, 0), (7, 1), (5, 5), (2, 1)][k % 4]
+        if k % 2:
+            r, q = realign_pair(rng, int(rng.integers(1, 40)), int(rng.integers(1, 90)), ins=int(rng.integers(0, 9)),
+                                sub=0.05, indel=0.05, alpha=ALPHA_WC)
+        else:
+            r, q = rand_seq(rng, int(rng.integers(1, 30)), ALPHA_WC), rand_seq(rng, int(rng.integers(1, 60)), ALPHA_WC)
+        for pref in (0, 1):
+            sc, e2, cg = oracle.realign(r, q, open_, ext, pref)
+            assert sc == _py_sg_dx_score(r, q, open_, ext)
+            rs, i_end, j_end = rescore_cigar(r, q, cg, open_, ext)
+            assert (rs, i_end, j_end - 1) == (sc, len(r), e2)
