@@ -29,6 +29,8 @@
  *   strk_o_count_locus             : strkit/call/call_locus.py:1079,1125-1161 (start-count feedback)
  *   strk_o_score_ref_boundaries    : repeats.py:23-43
  *   strk_o_ref_repeat_count        : repeats.py:73-192
+ *   strk_o_realign                 : strkit/call/realign.py:56-72 (parasail sg_dx_trace + CIGAR; tie rules restated
+ *                                    from memory of parasail's trace kernels — see the function's own header)
  */
 #include <stdint.h>
 #include <stdlib.h>

@@ -797,6 +797,7 @@ __device__ __forceinline__ void dp_kernel_body() {
     uint8_t* const Lw = lds + (threadIdx.x >> 6) * kWaveLdsBytes;
     const KArgsKernarg kernarg = (KArgsKernarg)__builtin_amdgcn_kernarg_segment_ptr();
     for (;;) {
+        __builtin_amdgcn_wave_barrier();   // the wave enters every iteration whole (see k_realign_dp)
         KArgsKernarg ap = kernarg;
         asm volatile("" : "+s"(ap));
         int32_t* const counters = ap->counters;
@@ -1197,6 +1198,7 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
     constexpr int perA = 64 / (8 << CA), perB = 64 / (8 << CB);   // reads per wave
     const int chA = (nA + perA - 1) / perA, chB = (nB + perB - 1) / perB;
     for (;;) {
+        __builtin_amdgcn_wave_barrier();   // the wave enters every iteration whole (see k_realign_dp)
         int c = 0;
         if ((threadIdx.x & 63) == 0) c = atomicAdd(&a.counters[kCntNextBand + SET], 1);
         c = __builtin_amdgcn_readfirstlane(c);
@@ -1255,6 +1257,7 @@ __global__ void __launch_bounds__(256) k_dp_long(KArgs a) {
     const int32_t* list = a.cls_list + (size_t)kLongClass * a.list_stride * 2;
 
     for (;;) {
+        __builtin_amdgcn_wave_barrier();   // the wave enters every iteration whole (see k_realign_dp)
         int it = 0;
         if (first) it = atomicAdd(&a.counters[kCntNextLong], 1);
         it = __builtin_amdgcn_readfirstlane(it);

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "strk_kernels.h"
 
 namespace strk {
@@ -32,6 +34,7 @@ constexpr int kRealignMaxCL = 32;
 constexpr int kRealignPadSym = 17;     // pad column: scores 0 against every row symbol
 constexpr int kRealignRowStride = 32;  // bytes per row-symbol row of the LDS score table
 constexpr int kRealignNeg = -(1 << 28);
+constexpr int kRealignStrip = 1024;    // row symbols staged in LDS per wave
 constexpr int kTagDiag = 8;            // bits 3:2 = 2
 constexpr int kTagMask = 12;
 constexpr int kFlagGiExt = 1, kFlagGdExt = 2;
@@ -79,7 +82,7 @@ __device__ __forceinline__ void realign_store(uint8_t* p, const unsigned (&w)[(C
 // One column tile of one pair.  Returns (in lane 63) the running maximum of the tile's last column.
 template <int CL, bool EXT0>
 __device__ __forceinline__ void realign_tile(const RealignArgs& a, const RealignPair& pr, int tile, const int8_t* tab,
-                                             const uint8_t* s_enc, int& best, int& bestj) {
+                                             const uint8_t* s_enc, uint8_t* s2buf, int& best, int& bestj) {
     constexpr int NW = (CL + 7) / 8;
     const int lane = threadIdx.x & 63;
     const int n2 = pr.n2, pad = pr.pad;
@@ -124,65 +127,101 @@ __device__ __forceinline__ void realign_tile(const RealignArgs& a, const Realign
     uint8_t* trace = a.trace + pr.trace_off + (size_t)tile * (size_t)(n2 + 63) * 64 * (CL / 2);
 
     const int steps = n2 + 63;
-    int chunk_sym = 0, chunk_h = 0, chunk_e = kRealignNeg + tagGi;
-    for (int t = 0; t < steps; ++t) {
-        const int j = t - lane;
-        if (a.dbg && lane == 0) a.dbg[(threadIdx.x >> 6) * 8 + 4] = t;
-        if ((t & 63) == 0) {   // next 64 row symbols / edge values, one per lane
-            const int jj = t + lane;
-            chunk_sym = (jj < n2 ? (int)s_enc[s2[jj]] : 16) * kRealignRowStride;
-            if (edge_in) {
-                chunk_h = jj < n2 ? edge_in[2 * jj] : 0;
-                chunk_e = jj < n2 ? edge_in[2 * jj + 1] : kRealignNeg + tagGi;
+    // Row symbols: 1 024 at a time are encoded into the wave's LDS strip (so that the step loop never waits on
+    // the memory counter its trace stores also use); each block of 64 steps takes its 64 symbols from there,
+    // one per lane.  Left-edge values of a later column tile come straight from the scratch array.
+    auto refill = [&](int t0) {
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < kRealignStrip / 64; ++u) {
+            const int jj = t0 + u * 64 + lane;
+            s2buf[u * 64 + lane] = jj < n2 ? s_enc[s2[jj]] : (uint8_t)16;
+        }
+        wave_lds_sync();
+    };
+    auto load_chunk = [&](int t0, int& c_sym, int& c_h, int& c_e) {
+        c_sym = (int)s2buf[(t0 & (kRealignStrip - 1)) + lane] * kRealignRowStride;
+        c_h = 0;
+        c_e = kRealignNeg + tagGi;
+        if (edge_in) {
+            const int jj = t0 + lane;
+            if (jj < n2) {
+                c_h = edge_in[2 * jj];
+                c_e = edge_in[2 * jj + 1];
             }
         }
-        if (t < 64 && j <= 0) {   // lanes that have not started yet keep their initial state
-#pragma unroll
-            for (int c = 0; c < CL; ++c) { Hrow[c] = bnd(ci0 + c); Gd[c] = kRealignNeg + tagGd; }
-            Hl_prev = bnd(ci0 - 1);
-        }
+    };
+    int chunk_sym = 0, chunk_h = 0, chunk_e = 0;
+    uint8_t* tp = trace + (size_t)lane * (CL / 2);
+
+    auto step = [&](auto ramp_tag, int t) {
+        constexpr bool RAMP = decltype(ramp_tag)::value;
+        // cross-lane traffic first, with all 64 lanes (lanes that have not started yet still pass the row symbol on)
         const int s_sym = __builtin_amdgcn_readlane(chunk_sym, t & 63);
         const int s_h = __builtin_amdgcn_readlane(chunk_h, t & 63);
         const int s_e = __builtin_amdgcn_readlane(chunk_e, t & 63);
         symrow = __builtin_amdgcn_update_dpp(s_sym, symrow, kDppWaveShr1, 0xf, 0xf, false);
         const int Hl = __builtin_amdgcn_update_dpp(s_h, lastH, kDppWaveShr1, 0xf, 0xf, false);
         const int El = __builtin_amdgcn_update_dpp(s_e, lastE, kDppWaveShr1, 0xf, 0xf, false);
+        if (!RAMP || t >= lane) {   // first 63 steps: lane l starts at step l and keeps its initial state until then
+            int w8[CL];
+#pragma unroll
+            for (int c = 0; c < CL; ++c) w8[c] = tab[symrow + (int)((apk[c / 4] >> (8 * (c % 4))) & 0xffu)];
 
-        int w8[CL];
+            unsigned word[NW];
 #pragma unroll
-        for (int c = 0; c < CL; ++c) w8[c] = tab[symrow + (int)((apk[c / 4] >> (8 * (c % 4))) & 0xffu)];
-
-        unsigned word[NW];
+            for (int q = 0; q < NW; ++q) word[q] = 0;
+            int diag = Hl_prev, upH = Hl, upE = El;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) word[q] = 0;
-        int diag = Hl_prev, upH = Hl, upE = El;
-#pragma unroll
-        for (int c = 0; c < CL; ++c) {
-            const int Dp = diag + w8[c];
-            const int Ei = max(EXT0 ? (upE | kFlagGiExt) : ((upE - e16) | kFlagGiExt), upH + kOpenGi);
-            const int Fj = max(EXT0 ? (Gd[c] | kFlagGdExt) : ((Gd[c] - e16) | kFlagGdExt), Hrow[c] + kOpenGd);
-            const int Hp = max(max(Dp, Ei), Fj);
-            const int Hc = Hp & ~15;
-            const unsigned x = ((unsigned)Ei & (unsigned)kFlagGiExt) | (unsigned)Fj;   // bits 1:0 = the two flags
-            const unsigned nib = ((unsigned)Hp & (unsigned)kTagMask) | (x & ~(unsigned)kTagMask);   // bits above 3 are shifted out below
-            word[c / 8] = __builtin_amdgcn_alignbit(nib, word[c / 8], 4);
-            diag = Hrow[c];
-            Hrow[c] = Hc;
-            Gd[c] = Fj;
-            upH = Hc;
-            upE = Ei;
-        }
-        Hl_prev = Hl;
-        lastH = upH;
-        lastE = upE;
-        realign_store<CL>(trace + ((size_t)t * 64 + lane) * (CL / 2), word);
-        if (lane == 63 && j >= 0 && j < n2) {
-            if (last_tile) {
-                if (upH > best) { best = upH; bestj = j; }
-            } else {
-                edge_out[2 * j] = upH;
-                edge_out[2 * j + 1] = upE;
+            for (int c = 0; c < CL; ++c) {
+                const int Dp = diag + w8[c];
+                const int Ei = max(EXT0 ? (upE | kFlagGiExt) : ((upE - e16) | kFlagGiExt), upH + kOpenGi);
+                const int Fj = max(EXT0 ? (Gd[c] | kFlagGdExt) : ((Gd[c] - e16) | kFlagGdExt), Hrow[c] + kOpenGd);
+                const int Hp = max(max(Dp, Ei), Fj);
+                const int Hc = Hp & ~15;
+                const unsigned x = ((unsigned)Ei & (unsigned)kFlagGiExt) | (unsigned)Fj;   // bits 1:0 = the two flags
+                unsigned nib;   // (Hp & 12) | (x & ~12); whatever lies above bit 3 is shifted out by the alignbit
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nib) : "v"(kTagMask), "v"(Hp), "v"(x));
+                word[c / 8] = __builtin_amdgcn_alignbit(nib, word[c / 8], 4);
+                diag = Hrow[c];
+                Hrow[c] = Hc;
+                Gd[c] = Fj;
+                upH = Hc;
+                upE = Ei;
             }
+            Hl_prev = Hl;
+            lastH = upH;
+            lastE = upE;
+            realign_store<CL>(tp, word);
+            // lane 63 holds row t - 63: a real row from t = 63 on (and t < n2 + 63 always)
+            if (lane == 63) {
+                if (last_tile) {
+                    if (upH > best) { best = upH; bestj = t - 63; }
+                } else {
+                    edge_out[2 * (t - 63)] = upH;
+                    edge_out[2 * (t - 63) + 1] = upE;
+                }
+            }
+        }
+        tp += 64 * (CL / 2);
+    };
+
+    for (int t0 = 0; t0 < steps; t0 += 64) {
+        if ((t0 & (kRealignStrip - 1)) == 0) {
+            if (a.dbg && lane == 0) a.dbg[(threadIdx.x >> 6) * 8 + 4] = t0;
+            refill(t0);
+        }
+        load_chunk(t0, chunk_sym, chunk_h, chunk_e);
+        const int tend = min(t0 + 64, steps);
+        if (t0 == 0) {
+            for (int t = 0; t < tend; ++t) step(std::true_type{}, t);
+        } else {
+            int t = t0;   // two steps per trip: the row registers swap roles instead of being copied
+            for (; t + 1 < tend; t += 2) {
+                step(std::false_type{}, t);
+                step(std::false_type{}, t + 1);
+            }
+            if (t < tend) step(std::false_type{}, t);
         }
     }
 }
@@ -193,6 +232,7 @@ template <int CL, bool EXT0>
 __global__ void __launch_bounds__(256) k_realign_dp(RealignArgs a, int first, int count, int qslot) {
     __shared__ int8_t tab[(kRealignPadSym + 1) * kRealignRowStride];   // 16*W + 8 per (row symbol, column symbol)
     __shared__ uint8_t s_enc[256];
+    __shared__ uint8_t s2strip[4 * kRealignStrip];
     s_enc[threadIdx.x] = c_enc[threadIdx.x];
     for (int i = threadIdx.x; i < (kRealignPadSym + 1) * kRealignRowStride; i += 256) {
         const int r = i / kRealignRowStride, c = i % kRealignRowStride;
@@ -203,7 +243,9 @@ __global__ void __launch_bounds__(256) k_realign_dp(RealignArgs a, int first, in
     __syncthreads();
     const int lane = threadIdx.x & 63;
     for (;;) {
-        // all 64 lanes take every iteration together
+        // All 64 lanes must take every iteration together.  Without this convergence point the compiler may
+        // merge the single-lane region that ends one iteration with the one that starts the next; the other 63
+        // lanes then run ahead, readfirstlane() returns THEIR (zero) item, and the wave re-runs item 0 for ever.
         __builtin_amdgcn_wave_barrier();
         int item = 0;
         if (a.dbg && lane == 0) a.dbg[(threadIdx.x >> 6) * 8 + 0] += 1;
@@ -220,7 +262,7 @@ __global__ void __launch_bounds__(256) k_realign_dp(RealignArgs a, int first, in
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
-            realign_tile<CL, EXT0>(a, pr, tile, tab, s_enc, best, bestj);
+            realign_tile<CL, EXT0>(a, pr, tile, tab, s_enc, s2strip + (threadIdx.x >> 6) * kRealignStrip, best, bestj);
         }
         if (a.dbg && lane == 0) a.dbg[(threadIdx.x >> 6) * 8 + 5] += 1;
         __builtin_amdgcn_wave_barrier();

@@ -28,18 +28,19 @@ def main():
         refs.append(ref.tobytes())
         reads.append(read.tobytes())
     realign_pairs(refs[:64], reads[:64])          # warm-up (workspace, code objects)
-    best = None
-    for _ in range(3):
+    best, all_ms = None, []
+    for _ in range(int(sys.argv[4]) if len(sys.argv) > 4 else 10):
         t = time.perf_counter()
         res, st = realign_pairs(refs, reads, with_stats=True)
         wall = time.perf_counter() - t
+        all_ms.append(round(st["kernel_ms"], 2))
         if best is None or st["kernel_ms"] < best[1]["kernel_ms"]:
             best = (wall, st)
     wall, st = best
     out = {"pairs": n, "ref_len": 141 + tr_len, "read_len": read_len, "kernel_ms": round(st["kernel_ms"], 3),
            "wall_ms": round(wall * 1e3, 1), "reads_per_s_kernel": round(n / (st["kernel_ms"] * 1e-3)),
            "gcups_kernel": round(st["dp_cells"] / (st["kernel_ms"] * 1e-3) / 1e9, 1),
-           "trace_GBps": round(st["exact_bytes"] / (st["kernel_ms"] * 1e-3) / 1e9, 1)}
+           "trace_GBps": round(st["exact_bytes"] / (st["kernel_ms"] * 1e-3) / 1e9, 1), "kernel_ms_all": all_ms}
     try:
         import oracle
         k = min(n, 8)
