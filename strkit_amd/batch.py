@@ -14,7 +14,7 @@ from . import _lib
 from .repeat_count_params import RepeatCountParams, default_read_rc_params
 from .synth import LocusBatch
 
-__all__ = ["count_loci", "score_table", "score_ref_table", "make_params", "batch_struct"]
+__all__ = ["count_loci", "score_table", "score_ref_table", "make_params", "batch_struct", "calc_adj_score", "filter_reads"]
 
 
 def make_params(rc_params: RepeatCountParams | None = None, feedback: bool = True, window: int = 0,
@@ -100,3 +100,49 @@ def score_ref_table(b: LocusBatch, lo, n, force_generic: bool = False, ctx: _lib
                                                 _ptr(sc), _ptr(eq), C.byref(st)))
     del keep
     return [(sc[off[r]:off[r + 1]], eq[off[r]:off[r + 1]]) for r in range(b.n_reads)]
+
+
+# ---- what the caller does with the four integers (strkit/call/call_locus.py:1172,1222-1252,1279-1283) ----------
+MIN_READ_ALIGN_SCORE = 0.1          # params.min_read_align_score default (strkit/call/params.py)
+EXTREMELY_LOW_READ_ADJ_SCORE = 0.1  # call_locus.py:75
+MAX_TERRIBLE_READS = 3              # params.max_terrible_reads default (call_locus.py:1236)
+
+
+def calc_adj_score(score, nfl, ntr, nfr):
+    """``STRkitAlignedSegmentSequenceDataForLocus.calc_adj_score`` (call_locus.py:1172): the alignment score per base
+    of the scored window (flanks + tract), ``None`` (NaN here) when the read holds no tract.  The Rust original is
+    not in the tree; a perfect read scores 2.0 as in docs/output_formats.md:102."""
+    score = np.asarray(score, np.float64)
+    total = np.asarray(nfl, np.int64) + np.asarray(ntr, np.int64) + np.asarray(nfr, np.int64)
+    adj = np.full(score.shape, np.nan)
+    ok = np.asarray(ntr) > 0
+    adj[ok] = score[ok] / total[ok]
+    return adj
+
+
+def filter_reads(b: LocusBatch, res: dict, min_read_align_score: float = MIN_READ_ALIGN_SCORE,
+                 max_terrible_reads: int = MAX_TERRIBLE_READS) -> dict:
+    """Per-read filter of the caller's loop, vectorised over a batch (call_locus.py:1222-1252):
+
+    * a read whose adjusted score is below ``min_read_align_score`` is skipped (``keep[r] = False``);
+    * such a read is "extremely poor" when its adjusted score is also below 0.1 (call_locus.py:75,1234; the
+      wall-clock half of that test never fires at GPU speeds); once a locus has seen MORE than
+      ``max_terrible_reads`` of them, in read order, it is not called (``locus_ok[l] = False``) and the reads
+      from that point on are not kept — reads before it were already recorded by the reference's loop.
+
+    Returns ``{"sc": adjusted scores (NaN = None), "keep": bool per read, "locus_ok": bool per locus}`` — ``sc`` and
+    ``res["cn"]`` of the kept reads are the ``read_dict`` entries of call_locus.py:1279-1283."""
+    adj = calc_adj_score(res["score"], b.nfl, b.ntr, b.nfr)
+    low = ~np.isnan(adj) & (adj < min_read_align_score)
+    terrible = low & (adj < EXTREMELY_LOW_READ_ADJ_SCORE)
+    keep = ~low
+    locus_ok = np.ones(b.n_loci, bool)
+    # running count of terrible reads inside each locus, in read order
+    csum = np.cumsum(terrible)
+    base = np.concatenate(([0], csum))[np.asarray(b.read_off[:-1], np.int64)]
+    read_locus = np.repeat(np.arange(b.n_loci), np.diff(b.read_off))
+    running = csum - base[read_locus]
+    voided = running > max_terrible_reads            # true from the read that tipped the locus over
+    keep &= ~voided
+    locus_ok[np.unique(read_locus[voided])] = False
+    return {"sc": adj, "keep": keep, "locus_ok": locus_ok}

@@ -153,3 +153,34 @@ def test_aligned_pair_matches_from_cigar():
     assert ac.query_coords.tolist() == [3, 4, 5, 8, 9]
     ac2 = get_aligned_pair_matches(cig, 100, 0)
     assert ac2.query_coords.tolist() == ac.ref_coords.tolist() and len(ac2) == 5 and ac2.pair_at_idx(2) == (103, 5)
+
+
+def test_adjusted_score_and_read_filters_follow_the_callers_loop():
+    """call_locus.py:1172,1222-1252 restated as a plain loop vs the vectorised host helper."""
+    from strkit_amd.batch import calc_adj_score, filter_reads
+    from strkit_amd.synth import make_config
+    b = make_config(2, n_loci=40)
+    rng = np.random.default_rng(4)
+    total = (b.nfl + b.ntr + b.nfr).astype(np.int64)
+    score = (2 * total).astype(np.int32)                       # perfect reads: adj 2.0 (docs/output_formats.md:102)
+    assert np.allclose(calc_adj_score(score, b.nfl, b.ntr, b.nfr), 2.0)
+    bad = rng.random(b.n_reads) < 0.12
+    score[bad] = (total[bad] * rng.uniform(-1.0, 0.15, int(bad.sum()))).astype(np.int32)
+    got = filter_reads(b, {"score": score})
+    for l in range(b.n_loci):
+        poor, ok = 0, True
+        for r in range(int(b.read_off[l]), int(b.read_off[l + 1])):
+            adj = score[r] / total[r]
+            if not ok:
+                assert not got["keep"][r]
+                continue
+            if adj < 0.1:
+                if adj < 0.1:
+                    poor += 1
+                    if poor > 3:
+                        ok = False
+                assert not got["keep"][r]
+                continue
+            assert got["keep"][r] and abs(got["sc"][r] - adj) < 1e-12
+        assert bool(got["locus_ok"][l]) == ok
+    assert (~got["locus_ok"]).any() and got["locus_ok"].any()
