@@ -1,0 +1,35 @@
+"""`python -m strkit_amd call <alignments.bam> --ref ref.fa --loci catalog.bed [--json out.json] [--realign]` — the
+subset of `strkit call` (strkit/entry.py:20-342) that the device backend covers: per-read copy numbers per locus."""
+from __future__ import annotations
+
+import argparse
+import sys
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="strkit_amd")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    c = sub.add_parser("call", help="per-read repeat counts for every catalog locus")
+    c.add_argument("read_file")
+    c.add_argument("--ref", required=True)
+    c.add_argument("--loci", required=True)
+    c.add_argument("--json", default="-")
+    c.add_argument("--flank-size", type=int, default=70)
+    c.add_argument("--min-avg-phred", type=int, default=13)
+    c.add_argument("--max-reads", type=int, default=250)
+    c.add_argument("--realign", action="store_true")
+    c.add_argument("--respect-ref", action="store_true")
+    a = ap.parse_args(argv)
+    from .frontend import call_sample, write_json
+    rep = call_sample(a.read_file, a.ref, a.loci, flank_size=a.flank_size, realign=a.realign,
+                      min_avg_phred=a.min_avg_phred, max_reads=a.max_reads, respect_ref=a.respect_ref)
+    if a.json == "-":
+        import json
+        json.dump(rep, sys.stdout, indent=1)
+    else:
+        write_json(rep, a.json)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

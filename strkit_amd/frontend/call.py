@@ -1,0 +1,140 @@
+"""`strkit call`-shaped driver over the device backend: alignment file + reference + catalog -> per-locus read copy
+numbers.  Follows the worker loop of strkit/call/call_sample.py:81-197 (blocks of loci, segments fetched once per
+block) and the per-locus path of strkit/call/call_locus.py:700-835 (reference window, reference copy number, adjusted
+boundaries), :837-958 (read coordinates, optional realignment), :1082-1161 (triples, start estimates) and
+:1172-1283 (adjusted score, filters, read_dict).  Allele calling, SNV phasing and VCF output stay with the reference
+(SURVEY.md §8f rank 4): the JSON written here carries the `reads` records they start from.
+"""
+from __future__ import annotations
+
+import json
+import time
+
+import numpy as np
+
+from .. import _lib
+from ..batch import count_loci, filter_reads
+from ..realign import realign_reads
+from ..repeat_count_params import get_reference_rc_params
+from ..repeats import get_ref_repeat_count
+from ..segment import calculate_seq_with_wildcards
+from ..synth import LocusBatch
+from .bam import BamFile, read_bam
+from .extract import (LowMeanBaseQual, MIN_AVG_PHRED, get_aligned_pairs, get_read_coords_from_matched_pairs,
+                      get_sequence_data_for_locus)
+from .fasta import Fasta
+from .loci import Locus, load_loci
+
+__all__ = ["call_sample", "write_json", "get_locus_with_ref_data", "MAX_READS"]
+
+MAX_READS = 250                 # params.max_reads default (strkit/call/params.py:21)
+DEFAULT_REF_MAX_ITERS = 100     # call_locus.py: default_ref_max_iters
+VCF_ANCHOR_SIZE = 5             # params.vcf_anchor_size default
+
+
+def get_locus_with_ref_data(locus: Locus, ref: Fasta, respect_ref: bool = False) -> dict | None:
+    """call_locus.py:736-835: reference window, reference copy number by the same counter, boundaries widened by the
+    offsets it found.  Returns None where the reference raises SkipLocus / InvalidLocus."""
+    try:
+        total = ref.fetch(locus.contig, locus.left_flank_coord, locus.right_flank_coord + 1)
+    except (IndexError, KeyError):
+        return None
+    off_l, off_r = locus.left_coord - locus.left_flank_coord, locus.right_coord - locus.left_flank_coord
+    fl, fr, tr = total[:off_l], total[off_r:-1], total[off_l:off_r]
+    if len(fl) < locus.flank_size or len(fr) < locus.flank_size:
+        return None                                           # "reference flank size too small"
+    n_run = "N" * locus.motif_size
+    if fl.endswith(n_run) or fr.startswith(n_run):
+        return None                                           # "reference has flanking N[...] sequence"
+    est = round(len(tr) / locus.motif_size)
+    (ref_cn, _), l_off, r_off, n_is, (fl2, tr2, fr2) = get_ref_repeat_count(
+        est, tr, fl, fr, locus.motif, ref_size=locus.right_coord - locus.left_coord, vcf_anchor_size=VCF_ANCHOR_SIZE,
+        rc_params=get_reference_rc_params("repalign", est, DEFAULT_REF_MAX_ITERS), respect_coords=respect_ref)
+    return {"ref_cn": ref_cn, "ref_total_seq": total, "ref_seq": tr2, "ref_left_flank_seq": fl2, "ref_right_flank_seq": fr2,
+            "left_coord_adj": locus.left_coord if respect_ref else locus.left_coord - max(0, l_off),
+            "right_coord_adj": locus.right_coord if respect_ref else locus.right_coord + max(0, r_off)}
+
+
+def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size: int = 70, realign: bool = False,
+                min_avg_phred: int = MIN_AVG_PHRED, max_reads: int = MAX_READS, respect_ref: bool = False,
+                ctx: _lib.Context | None = None) -> dict:
+    bam = read_bam(bam) if isinstance(bam, str) else bam
+    ref = Fasta(ref) if isinstance(ref, str) else ref
+    ctx = ctx or _lib.default_context()
+    t0 = time.perf_counter()
+    results: list[dict] = []
+    for block in load_loci(loci_file, flank_size, contigs=set(bam.references) & set(ref.references)):
+        prepared = []                     # (locus, ref data, [(segment, query_coords, ref_coords) ...])
+        realign_jobs = []                 # (index into prepared, index of the segment)
+        for locus in block:
+            rd = get_locus_with_ref_data(locus, ref, respect_ref)
+            if rd is None:
+                results.append({"locus_index": locus.t_idx, "locus_id": locus.locus_id, "contig": locus.contig,
+                                "start": locus.left_coord, "end": locus.right_coord, "motif": locus.motif, "skipped": True})
+                continue
+            segs = bam.fetch(locus.contig, locus.left_flank_coord, locus.right_flank_coord)[:max_reads]
+            entries = []
+            for seg in segs:
+                if realign and seg.soft_clip_overlaps_locus(locus):
+                    realign_jobs.append((len(prepared), len(entries)))
+                entries.append([seg, None, False])
+            prepared.append((locus, rd, entries))
+        if realign_jobs:                  # every soft-clipped read of the block in one device call (realign.py:75-154)
+            refs_, reads_, lfcs = [], [], []
+            for pi, ei in realign_jobs:
+                locus, rd, entries = prepared[pi]
+                seg = entries[ei][0]
+                refs_.append(rd["ref_total_seq"])
+                reads_.append(calculate_seq_with_wildcards(seg.query_sequence, seg.query_qualities, 3))
+                lfcs.append(locus.left_flank_coord)
+            for (pi, ei), ac in zip(realign_jobs, realign_reads(refs_, reads_, lfcs, flank_size, context=ctx)):
+                if ac is not None:
+                    prepared[pi][2][ei][1] = (ac.query_coords, ac.ref_coords)
+                    prepared[pi][2][ei][2] = True
+        # triples of every read of the block -> one batched device call
+        loci_reads, meta = [], []
+        for locus, rd, entries in prepared:
+            triples, names = [], []
+            for seg, pairs, realigned in entries:
+                qc, rc = pairs if pairs is not None else get_aligned_pairs(seg)
+                coords = get_read_coords_from_matched_pairs(locus.left_flank_coord, rd["left_coord_adj"],
+                                                            rd["right_coord_adj"], locus.right_flank_coord, qc, rc)
+                if coords.is_incomplete():
+                    continue
+                try:
+                    sd = get_sequence_data_for_locus(seg, coords, flank_size, min_avg_phred)
+                except LowMeanBaseQual:
+                    continue
+                triples.append((sd.flank_left_seq_wc[-flank_size:], sd.tr_seq_wc, sd.flank_right_seq_wc[:flank_size]))
+                names.append((seg.name, seg.strand, realigned, len(sd.tr_seq)))
+            loci_reads.append((locus.motif, triples))
+            meta.append(names)
+        if not prepared:
+            continue
+        batch = LocusBatch.from_reads(loci_reads)
+        res = count_loci(batch, ctx=ctx) if batch.n_reads else {k: np.zeros(0, np.int32) for k in ("cn", "score", "n_iters", "start")}
+        flt = filter_reads(batch, res) if batch.n_reads else {"sc": np.zeros(0), "keep": np.zeros(0, bool), "locus_ok": np.ones(batch.n_loci, bool)}
+        for li, (locus, rd, _) in enumerate(prepared):
+            r0, r1 = int(batch.read_off[li]), int(batch.read_off[li + 1])
+            kept = [r for r in range(r0, r1) if flt["keep"][r]]
+            reads = {}
+            for r in kept:
+                name, strand, realigned, sl = meta[li][r - r0]
+                sc = float(flt["sc"][r])
+                reads[name] = {"s": strand, "cn": int(res["cn"][r]), "w": 1.0 / len(kept),
+                               "sc": None if np.isnan(sc) else sc, "sl": sl, **({"realn": True} if realigned else {})}
+            results.append({"locus_index": locus.t_idx, "locus_id": locus.locus_id, "contig": locus.contig,
+                            "start": locus.left_coord, "end": locus.right_coord,
+                            "start_adj": rd["left_coord_adj"], "end_adj": rd["right_coord_adj"], "motif": locus.motif,
+                            "ref_cn": int(rd["ref_cn"]), "ref_start_anchor": rd["ref_left_flank_seq"][-VCF_ANCHOR_SIZE:].upper(),
+                            "called": bool(flt["locus_ok"][li]) and len(kept) > 0,
+                            "reads": reads if flt["locus_ok"][li] else {}})
+    results.sort(key=lambda r: r["locus_index"])
+    return {"caller": {"name": "strkit_amd", "version": _lib.load().strk_version().decode()},
+            "parameters": {"flank_size": flank_size, "realign": realign, "min_avg_phred": min_avg_phred, "max_reads": max_reads},
+            "runtime": time.perf_counter() - t0, "contigs": bam.references, "results": results}
+
+
+def write_json(report: dict, path: str) -> None:
+    with open(path, "w") as fh:
+        json.dump(report, fh, indent=1)

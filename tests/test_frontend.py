@@ -1,0 +1,135 @@
+"""CPU tests of the minimal front end (catalog loader, BAM/FASTA, read-coordinate extraction).  The parameter tables
+of the first four tests are the reference's own vectors (tests/test_caller_loci_fns.py:8-35,
+tests/test_caller_utils.py:1-11, tests/data/test_loci.bed) used as data."""
+import os
+
+import numpy as np
+import pytest
+
+from strkit_amd.frontend import (Fasta, Locus, LocusValidationError, find_pair_by_ref_pos, get_aligned_pairs,
+                                 get_read_coords_from_matched_pairs, get_sequence_data_for_locus, load_loci,
+                                 parse_last_column, read_bam, valid_motif, validate_locus, write_bam)
+from strkit_amd.frontend.extract import LowMeanBaseQual
+from strkit_amd.frontend.synth_dataset import make_dataset
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("motif,valid", [("CAG", True), ("CAGN", True), ("CAGX", False), ("(CAG)n", False), ("XX", False)])
+def test_valid_motif(motif, valid):
+    assert valid_motif(motif) == valid
+
+
+def test_validate_locus():
+    with pytest.raises(LocusValidationError):
+        validate_locus(Locus(1, "locus1", "1", 1000, 1000, "CAG", 70))      # start == end
+    with pytest.raises(LocusValidationError):
+        validate_locus(Locus(1, "locus1", "1", 1000, 1200, "(CAG)n", 70))   # invalid motif
+    validate_locus(Locus(1, "locus1", "1", 1000, 1200, "CAG", 70))
+
+
+@pytest.mark.parametrize("t_idx,val,parsed", [
+    (0, "CAG", {"id": "locus0", "motif": "CAG"}),
+    (0, "MOTIF=CAG", {"id": "locus0", "motif": "CAG"}),
+    (0, "Motif = CAG", {"id": "locus0", "motif": "CAG"}),
+    (0, "ID=HTT; MOTIF = CAG", {"id": "HTT", "motif": "CAG"}),
+    (0, "ID = HTT ;motif = CAG", {"id": "HTT", "motif": "CAG"}),
+    (0, "id=HTT ; motif=cag", {"id": "HTT", "motif": "CAG"}),
+])
+def test_parse_last_column(t_idx, val, parsed):
+    assert parse_last_column(t_idx, val) == parsed
+
+
+def test_find_pair_by_ref_pos_vectors():
+    pairs_r = [1000, 1001, 1003, 1004, 1005, 1006, 1008, 1009]
+    assert find_pair_by_ref_pos(pairs_r, 1004) == (3, True)
+    assert find_pair_by_ref_pos(pairs_r, 1007) == (6, False)
+
+
+@pytest.mark.parametrize("val", ["ID=HTT", "MOTIF=", "FOO=1;MOTIF=CAG", "ID=a=b;MOTIF=CAG", "MOTIF=CAG;"])
+def test_parse_last_column_rejects(val):
+    with pytest.raises(LocusValidationError):
+        parse_last_column(3, val)
+
+
+def test_reference_catalog_file_and_blocks(tmp_path):
+    blocks = load_loci(os.path.join(HERE, "golden", "ref_test_loci.bed"))
+    flat = [l for b in blocks for l in b]
+    assert [(l.contig, l.left_coord, l.right_coord, l.motif) for l in flat] == [
+        ("chr1", 200, 300, "ACAA"), ("chr1", 300, 400, "GA"), ("chr1", 350, 450, "GAGA"), ("chr2", 100, 200, "CAG")]
+    assert [l.contig for l in blocks[-1]] == ["chr2"] and all(len({l.contig for l in b}) == 1 for b in blocks)
+    assert flat[0].left_flank_coord == 130 and flat[0].right_flank_coord == 370 and flat[3].locus_id == "locus4"
+    # block rules: at most 200 loci, split at gaps of more than 20 000 bases, unknown contigs dropped
+    p = tmp_path / "many.bed"
+    rows = [f"chr1\t{1000 + 300 * i}\t{1100 + 300 * i}\tCAG" for i in range(450)]
+    rows += ["chr1\t900000\t900100\tID=far;MOTIF=ac", "chrUn\t5\t50\tCAG", "# comment", ""]
+    p.write_text("\n".join(rows) + "\n")
+    blocks = load_loci(str(p), contigs={"chr1"})
+    assert [len(b) for b in blocks] == [200, 200, 50, 1] and blocks[-1][0].motif == "AC" and blocks[-1][0].locus_id == "far"
+    assert [len(b) for b in load_loci(str(p), contigs={"chr1"}, processes=8)] == [56] * 8 + [2, 1]
+
+
+def test_bam_round_trip_and_fetch(tmp_path):
+    recs = [dict(name="r1", flag=0, contig="chr1", pos=100, cigar=[(5, "S"), (10, "M"), (2, "I"), (8, "M"), (3, "D"), (5, "=")],
+                 seq="ACGTN" * 6, qual=np.arange(30)),
+            dict(name="r2", flag=16, contig="chr1", pos=400, cigar=[(7, "M")], seq="ACGTACG", qual=None),
+            dict(name="r3", flag=0, contig="chr2", pos=0, cigar=[(70000, "M")], seq="A" * 70000, qual=np.full(70000, 30))]
+    path = str(tmp_path / "t.bam")
+    write_bam(path, [("chr1", 1000), ("chr2", 80000)], recs)
+    b = read_bam(path)
+    assert b.references == ["chr1", "chr2"] and [s.name for s in b.segments] == ["r1", "r2", "r3"]
+    s = b.segments[0]
+    assert (s.start, s.end, s.length, s.is_reverse, s.soft_clips()) == (100, 126, 30, False, (5, 0))
+    assert s.query_sequence == "ACGTN" * 6 and s.query_qualities.tolist() == list(range(30))
+    assert b.segments[1].query_qualities is None and b.segments[1].is_reverse and b.segments[2].length == 70000
+    assert [x.name for x in b.fetch("chr1", 120, 130)] == ["r1"] and b.fetch("chr1", 126, 400) == []
+    assert [x.name for x in b.fetch("chr1", 126, 401)] == ["r2"] and b.fetch("chrX", 0, 10) == []
+    q, r = get_aligned_pairs(s)
+    assert q.tolist() == list(range(5, 15)) + list(range(17, 30)) and r.tolist() == list(range(100, 118)) + list(range(121, 126))
+
+
+def test_read_coordinates_put_boundary_insertions_into_the_tract():
+    # ref: flank [0,10) tract [10,16) flank [16,26); read has 6 extra bases inserted right after the tract's last base
+    class Seg:
+        start = 0
+        cigar = np.array([(16 << 4) | 0, (6 << 4) | 1, (10 << 4) | 0], np.uint32)
+        query_sequence = "A" * 10 + "CAGCAG" + "CAGCAG" + "T" * 10
+        query_qualities = np.full(32, 30)
+    q, r = get_aligned_pairs(Seg)
+    c = get_read_coords_from_matched_pairs(0, 10, 16, 26, q, r)
+    assert (c.left_flank_start, c.left_flank_end, c.right_flank_start, c.right_flank_end) == (0, 10, 22, 32)
+    sd = get_sequence_data_for_locus(Seg, c, 10)
+    assert (sd.flank_left_seq_wc, sd.tr_seq_wc, sd.flank_right_seq_wc, sd.tr_len_with_flank) == ("A" * 10, "CAG" * 4, "T" * 10, 32)
+    assert sd.get_est_copy_num(3) == 4
+    # ... and right before its first base; a read that stops short of a flank end is incomplete
+    Seg.cigar = np.array([(10 << 4) | 0, (6 << 4) | 1, (16 << 4) | 0], np.uint32)
+    q, r = get_aligned_pairs(Seg)
+    c = get_read_coords_from_matched_pairs(0, 10, 16, 26, q, r)
+    assert (c.left_flank_end, c.right_flank_start) == (10, 22)
+    assert get_read_coords_from_matched_pairs(0, 10, 16, 40, q, r).is_incomplete()
+    # low-quality tract bases: wildcards at <= 3, LowMeanBaseQual under the mean threshold
+    Seg.query_qualities = np.full(32, 30)
+    Seg.query_qualities[12:14] = 2
+    assert get_sequence_data_for_locus(Seg, c, 10).tr_seq_wc == "CAXXAGCAGCAG"
+    Seg.query_qualities[10:22] = 5
+    with pytest.raises(LowMeanBaseQual):
+        get_sequence_data_for_locus(Seg, c, 10)
+
+
+def test_synthetic_dataset_extraction_recovers_the_alleles(tmp_path):
+    t = make_dataset(str(tmp_path), n_loci=6, reads_per_locus=6, read_len=1200, seed=3)
+    bam, ref = read_bam(t["paths"]["bam"]), Fasta(t["paths"]["ref"])
+    (block,) = load_loci(t["paths"]["loci"])
+    for locus, truth in zip(block, t["loci"]):
+        assert (locus.left_coord, locus.right_coord, locus.motif) == (truth["start"], truth["end"], truth["motif"])
+        assert ref.fetch(locus.contig, locus.left_coord, locus.right_coord) == truth["motif"] * truth["ref_cn"]
+        segs = bam.fetch(locus.contig, locus.left_flank_coord, locus.right_flank_coord)
+        assert len(segs) == 6
+        for s in segs:
+            q, r = get_aligned_pairs(s)
+            c = get_read_coords_from_matched_pairs(locus.left_flank_coord, locus.left_coord, locus.right_coord,
+                                                   locus.right_flank_coord, q, r)
+            sd = get_sequence_data_for_locus(s, c, 70)
+            assert sd.tr_seq == truth["motif"] * truth["reads"][s.name]
+            assert sd.flank_left_seq_wc[-70:] == ref.fetch(locus.contig, locus.left_flank_coord, locus.left_coord)
+            assert sd.flank_right_seq_wc[:70] == ref.fetch(locus.contig, locus.right_coord, locus.right_flank_coord)
