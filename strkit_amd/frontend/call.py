@@ -55,22 +55,29 @@ def get_locus_with_ref_data(locus: Locus, ref: Fasta, respect_ref: bool = False)
             "right_coord_adj": locus.right_coord if respect_ref else locus.right_coord + max(0, r_off)}
 
 
+def _locus_dict(locus: Locus) -> dict:
+    """STRkitLocus.to_dict() + the always-present call keys (call_locus.py:1013-1017, json_report.py:69-74)."""
+    return {"locus_index": locus.t_idx, "locus_id": locus.locus_id, "contig": locus.contig, "start": locus.left_coord,
+            "end": locus.right_coord, "motif": locus.motif, "annotations": [], "assign_method": None, "call": None,
+            "call_95_cis": None, "call_99_cis": None}
+
+
 def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size: int = 70, realign: bool = False,
                 min_avg_phred: int = MIN_AVG_PHRED, max_reads: int = MAX_READS, respect_ref: bool = False,
-                ctx: _lib.Context | None = None) -> dict:
+                sample_id: str | None = None, ctx: _lib.Context | None = None) -> dict:
     bam = read_bam(bam) if isinstance(bam, str) else bam
     ref = Fasta(ref) if isinstance(ref, str) else ref
     ctx = ctx or _lib.default_context()
     t0 = time.perf_counter()
     results: list[dict] = []
+    n_depth = 0
     for block in load_loci(loci_file, flank_size, contigs=set(bam.references) & set(ref.references)):
         prepared = []                     # (locus, ref data, [(segment, query_coords, ref_coords) ...])
         realign_jobs = []                 # (index into prepared, index of the segment)
         for locus in block:
             rd = get_locus_with_ref_data(locus, ref, respect_ref)
             if rd is None:
-                results.append({"locus_index": locus.t_idx, "locus_id": locus.locus_id, "contig": locus.contig,
-                                "start": locus.left_coord, "end": locus.right_coord, "motif": locus.motif, "skipped": True})
+                results.append(_locus_dict(locus))    # SkipLocus: locus fields + empty call (call_locus.py:1032-1036)
                 continue
             segs = bam.fetch(locus.contig, locus.left_flank_coord, locus.right_flank_coord)[:max_reads]
             entries = []
@@ -123,16 +130,27 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
                 sc = float(flt["sc"][r])
                 reads[name] = {"s": strand, "cn": int(res["cn"][r]), "w": 1.0 / len(kept),
                                "sc": None if np.isnan(sc) else sc, "sl": sl, **({"realn": True} if realigned else {})}
-            results.append({"locus_index": locus.t_idx, "locus_id": locus.locus_id, "contig": locus.contig,
-                            "start": locus.left_coord, "end": locus.right_coord,
-                            "start_adj": rd["left_coord_adj"], "end_adj": rd["right_coord_adj"], "motif": locus.motif,
-                            "ref_cn": int(rd["ref_cn"]), "ref_start_anchor": rd["ref_left_flank_seq"][-VCF_ANCHOR_SIZE:].upper(),
-                            "called": bool(flt["locus_ok"][li]) and len(kept) > 0,
-                            "reads": reads if flt["locus_ok"][li] else {}})
+            row = _locus_dict(locus)
+            row["ref_cn"] = int(rd["ref_cn"])
+            if not respect_ref:
+                row["start_adj"], row["end_adj"] = rd["left_coord_adj"], rd["right_coord_adj"]
+            row["ref_start_anchor"] = rd["ref_left_flank_seq"][-VCF_ANCHOR_SIZE:].upper()
+            # allele calling is not part of this backend: the record stops where call_locus.py:1300 starts
+            row["peaks"], row["read_peaks_called"] = None, False
+            row["reads"] = reads if flt["locus_ok"][li] else {}
+            n_depth += len(row["reads"])
+            results.append(row)
     results.sort(key=lambda r: r["locus_index"])
-    return {"caller": {"name": "strkit_amd", "version": _lib.load().strk_version().decode()},
-            "parameters": {"flank_size": flank_size, "realign": realign, "min_avg_phred": min_avg_phred, "max_reads": max_reads},
-            "runtime": time.perf_counter() - t0, "contigs": bam.references, "results": results}
+    # same top-level layout as the reference's report (strkit/call/output/json_report.py:37-60,127-154)
+    return {"sample_id": sample_id,
+            "caller": {"name": "strkit_amd", "version": _lib.load().strk_version().decode()},
+            "parameters": {"flank_size": flank_size, "realign": realign, "min_avg_phred": min_avg_phred,
+                           "max_reads": max_reads, "respect_ref": respect_ref, "rc_method": "repalign"},
+            "contigs": sorted({r["contig"] for r in results}),
+            "catalog": {"num_loci": len(results)},
+            "results": results,
+            "avg_read_depth": n_depth / max(1, sum(1 for r in results if "reads" in r)),
+            "runtime": time.perf_counter() - t0}
 
 
 def write_json(report: dict, path: str) -> None:
