@@ -126,3 +126,31 @@ def test_bad_input(gpu_ctx):
     with pytest.raises(_lib.StrkError):
         realign_pairs(["ACGT"], ["ACGT"], open_penalty=3, extend_penalty=5)
     assert realign_pairs([], []) == []
+
+
+def test_hifi_read_shape_rate_and_parity(gpu_ctx, capsys):
+    """The shape tools/bench_realign.py times (441-base window, 15 kb read): parity on a sample and, for the record,
+    the rate of the CPU restatement next to the device's (printed with -s; reported in profiles/README.md)."""
+    import time
+    rng = np.random.default_rng(12)
+    refs, reads = [], []
+    for _ in range(128):
+        ref = rand_seq(rng, 441)
+        read = list(rand_seq(rng, 15000))
+        pos = int(rng.integers(0, 15000 - 441 - 400))
+        body = ref[:70] + rand_seq(rng, int(rng.integers(0, 300))) + ref[70:]
+        read[pos:pos + len(body)] = body
+        refs.append(ref)
+        reads.append("".join(read))
+    realign_pairs(refs[:8], reads[:8])
+    t = time.perf_counter()
+    got, st = realign_pairs(refs, reads, with_stats=True)
+    gpu_wall = time.perf_counter() - t
+    t = time.perf_counter()
+    exp = [oracle.realign(refs[i], reads[i]) for i in range(8)]
+    cpu = time.perf_counter() - t
+    for i in range(8):
+        assert (got[i][0], got[i][1], got[i][2].tolist()) == (exp[i][0], exp[i][1], exp[i][2].tolist())
+    with capsys.disabled():
+        print(f"\n[realign 441 x 15000] CPU restatement {8 / cpu:.1f} reads/s on one core; device {128 / gpu_wall:.0f} reads/s "
+              f"wall for 128 reads ({st['kernel_ms']:.2f} ms of kernels)")

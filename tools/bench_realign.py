@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of strk_realign on the shape realign.py:56-63 sees: reference window 2*70 + TR + 1 against a
-whole wildcarded HiFi read (~15 kb).  Prints reads/s, GCUPS (HIP-event kernel time) and the CPU oracle's rate
-on a small sample.  Usage: python tools/bench_realign.py [n_pairs] [tr_len] [read_len]"""
+whole wildcarded HiFi read (~15 kb).  Prints reads/s and GCUPS (HIP-event kernel time).  Parity and the CPU
+restatement's rate on the same shape are in tests/test_gpu_realign.py::test_hifi_read_shape_rate_and_parity.  Usage: python tools/bench_realign.py [n_pairs] [tr_len] [read_len]"""
 import json
 import sys
 import time
@@ -41,17 +41,6 @@ def main():
            "wall_ms": round(wall * 1e3, 1), "reads_per_s_kernel": round(n / (st["kernel_ms"] * 1e-3)),
            "gcups_kernel": round(st["dp_cells"] / (st["kernel_ms"] * 1e-3) / 1e9, 1),
            "trace_GBps": round(st["exact_bytes"] / (st["kernel_ms"] * 1e-3) / 1e9, 1), "kernel_ms_all": all_ms}
-    try:
-        import oracle
-        k = min(n, 8)
-        t = time.perf_counter()
-        exp = [oracle.realign(refs[i].decode(), reads[i].decode()) for i in range(k)]
-        dt = time.perf_counter() - t
-        out["cpu_oracle_reads_per_s_1core"] = round(k / dt, 1)
-        out["parity_sample_ok"] = all(res[i][0] == exp[i][0] and res[i][1] == exp[i][1] and
-                                      res[i][2].tolist() == exp[i][2].tolist() for i in range(k))
-    except Exception as e:  # noqa: BLE001
-        out["cpu_oracle"] = repr(e)
     print(json.dumps(out))
 
 
