@@ -59,6 +59,26 @@ def main() -> None:
     # 3. scoring matrix
     with open(os.path.join(HERE, "dna_matrix.json"), "w") as f:
         json.dump({"alphabet": "ACGTRYSWKMBDHVNX*", "matrix": oracle.matrix().tolist()}, f)
+    # 4. realignment (strk_o_realign): score, end and CIGAR under both gap preferences and several gap models
+    from helpers import cigar_tuples, rand_seq, realign_pair
+    rng2 = np.random.default_rng(20261004)
+    cases = []
+    for k in range(36):
+        open_, ext = [(7, 0), (7, 0), (7, 1), (5, 5), (2, 1), (0, 0)][k % 6]
+        alpha = [ALPHA_WC, "AC", ALPHA_IUPAC, "ACGT"][k % 4]
+        if k % 3:
+            r, q = realign_pair(rng2, int(rng2.integers(1, 90)), int(rng2.integers(1, 260)), ins=int(rng2.integers(0, 25)),
+                                dele=int(rng2.integers(0, 8)), sub=0.04, indel=0.04, alpha=alpha)
+        else:
+            r, q = rand_seq(rng2, int(rng2.integers(1, 40)), alpha), rand_seq(rng2, int(rng2.integers(1, 120)), alpha)
+        if k % 5 == 0:
+            q = q.lower()
+        for pref in (0, 1):
+            sc, e2, cg = oracle.realign(r, q, open_, ext, pref)
+            cases.append({"ref": r, "read": q, "open": open_, "extend": ext, "gap_pref": pref, "score": sc, "end_ref": e2,
+                          "cigar": "".join(f"{n}{o}" for n, o in cigar_tuples(cg))})
+    with open(os.path.join(HERE, "realign_cases.json"), "w") as f:
+        json.dump(cases, f, separators=(",", ":"))
     print("wrote", sorted(x for x in os.listdir(HERE) if x.endswith(".json")))
 
 

@@ -154,3 +154,18 @@ def test_hifi_read_shape_rate_and_parity(gpu_ctx, capsys):
     with capsys.disabled():
         print(f"\n[realign 441 x 15000] CPU restatement {8 / cpu:.1f} reads/s on one core; device {128 / gpu_wall:.0f} reads/s "
               f"wall for 128 reads ({st['kernel_ms']:.2f} ms of kernels)")
+
+
+def test_golden_realign_cases(gpu_ctx):
+    import json
+    import os
+    from strkit_amd.realign import cigar_to_string
+    with open(os.path.join(os.path.dirname(__file__), "golden", "realign_cases.json")) as f:
+        cases = json.load(f)
+    groups = {}
+    for c in cases:
+        groups.setdefault((c["open"], c["extend"], c["gap_pref"]), []).append(c)
+    for (open_, ext, pref), cs in groups.items():
+        got = realign_pairs([c["ref"] for c in cs], [c["read"] for c in cs], open_, ext, pref)
+        for c, (sc, e2, cg) in zip(cs, got):
+            assert (sc, e2, cigar_to_string(cg)) == (c["score"], c["end_ref"], c["cigar"])

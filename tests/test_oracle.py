@@ -221,3 +221,13 @@ def test_realign_matches_python_restatement_and_its_own_cigar():
             assert sc == _py_sg_dx_score(r, q, open_, ext)
             rs, i_end, j_end = rescore_cigar(r, q, cg, open_, ext)
             assert (rs, i_end, j_end - 1) == (sc, len(r), e2)
+
+
+def test_golden_realign_cases():
+    from helpers import cigar_tuples
+    with open(os.path.join(GOLD, "realign_cases.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 72
+    for c in cases:
+        sc, e2, cg = oracle.realign(c["ref"], c["read"], c["open"], c["extend"], c["gap_pref"])
+        assert (sc, e2, "".join(f"{n}{o}" for n, o in cigar_tuples(cg))) == (c["score"], c["end_ref"], c["cigar"])
