@@ -22,6 +22,10 @@ import os
 import sys
 import time
 
+# Four calls in flight use four HIP streams besides the default one; the runtime's default of 4 hardware queues would
+# make two of them share a queue (and serialise).  Read by the HIP runtime at its initialisation, so set before it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -84,7 +88,7 @@ def main() -> None:
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--no-dedupe", action="store_true", help="score identical reads of a locus separately")
     ap.add_argument("--no-band", action="store_true", help="exact kernels only (no banded first pass)")
-    ap.add_argument("--pipeline", type=int, default=3, help="batched calls in flight (contexts/streams)")
+    ap.add_argument("--pipeline", type=int, default=4, help="batched calls in flight (contexts/streams)")
     ap.add_argument("--cpu-sample-loci", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (self-test)")

@@ -67,6 +67,9 @@ def load(build: bool = True):
     with _lib_lock:
         if _lib is not None:
             return _lib
+        # Callers that keep several batched calls in flight (one context + stream each) need a
+        # hardware queue per stream; the HIP runtime's default is 4 for the whole process.  Read at HIP initialisation.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         path = _build.LIB_PATH
         if build and _build.stale():
             try:

@@ -94,6 +94,11 @@ struct strk_ctx {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // call start, exact DP start/end, call end, band start/end
     size_t scratch_ints = 0;
     int band_cooldown = 0;   // > 0: the band kernel is switched off for that many calls (too many certificates failed)
+    // work-queue lengths of the previous finished call (wave chunks), used to size the persistent grids of the
+    // kernels that usually have little or nothing to do: an idle block still claims its 70-80 KB of LDS on a CU
+    // and so delays the band blocks of the calls it overlaps with
+    bool hist_valid = false;
+    int hist_band_mode = 0, hist_reads = 1, hist_exact_chunks = 0, hist_wide_chunks = 0, hist_long = 0;
     // one submitted-but-not-finished batched call (strk_submit_loci_device .. strk_finish)
     bool pending = false;
     strk_batch p_batch;
@@ -196,27 +201,40 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
                      hipStream_t st, bool time_dp) {
     hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, a, mode, d_items, n_items, force_generic);
     static const int tune = getenv("STRKIT_AMD_DP_BLOCKS") ? atoi(getenv("STRKIT_AMD_DP_BLOCKS")) : 0;   // tuning aid
-    // a call that shares the device with other calls in flight takes half the CU slots per kernel, so that the
-    // tail of one call and the head of the next co-run (this call is counted already)
-    const int share = g_calls_in_flight.load(std::memory_order_relaxed) > 1 ? 2 : 1;
+    // a call that shares the device with other calls in flight takes three quarters of the CU slots per kernel, so
+    // that the tail of one call and the head of the next co-run (this call is counted already); measured on the
+    // bench workload with four calls in flight: 1/2 -> 117 M reads/s, 3/4 and 7/8 -> 125 M, all -> 120 M
+    const int quarters = g_calls_in_flight.load(std::memory_order_relaxed) > 1 ? 3 : 4;
+    // expected chunks of the sparsely used kernels, from the previous call of this context (same band mode), scaled
+    // to this batch with 50 % head-room; without history every grid is the full resident one.  A grid that turns
+    // out too small only makes that kernel slower: every wave pulls chunks until the queue is empty.
+    const bool hist = mode == 0 && c->hist_valid && c->hist_band_mode == a.band_mode;
+    auto predicted_blocks = [&](int chunks, int full) {
+        if (!hist) return full;
+        const double scaled = (double)chunks * std::max(1, a.n_reads) / std::max(1, c->hist_reads);
+        const int blocks = chunks == 0 ? 1 : (int)(scaled * 1.5 / 4.0) + 2;
+        return std::max(1, std::min(full, blocks));
+    };
     if (a.band_mode && mode == 0 && !force_generic) {
         // banded first pass: certified reads are done, the others are appended to the exact lists below
-        const int blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU / share, (a.list_stride + 3) / 4));
+        const int blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * quarters / 4, (a.list_stride + 3) / 4));
         if (time_dp) (void)hipEventRecord(c->ev[4], st);
         hipLaunchKernelGGL(k_dp_band, dim3(blocks), dim3(256), 0, st, a);
         if (time_dp) (void)hipEventRecord(c->ev[5], st);
-        hipLaunchKernelGGL(k_dp_band_wide, dim3(blocks), dim3(256), 0, st, a);   // long windows (exits at once if none)
+        hipLaunchKernelGGL(k_dp_band_wide, dim3(predicted_blocks(c->hist_wide_chunks, blocks)), dim3(256), 0, st, a);   // long windows
     }
     if (time_dp) (void)hipEventRecord(c->ev[1], st);
     if (!force_generic) {
         // persistent-style grid: every wave pulls chunks from the device-side queue until it is empty
         constexpr int kBlocksPerCU = std::max(1, std::min(8, (160 * 1024) / (4 * kWaveLdsBytes + kLdsSlack + 1024)));
-        const int blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBlocksPerCU / share, (a.list_stride + 3) / 4));
+        const int full = std::max(1, std::min(tune > 0 ? tune : 256 * kBlocksPerCU * quarters / 4, (a.list_stride + 3) / 4));
+        const int blocks = a.ref_mode ? full : predicted_blocks(c->hist_exact_chunks, full);
         if (a.ref_mode) hipLaunchKernelGGL(k_dp_ref, dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);
     }
     if (time_dp) (void)hipEventRecord(c->ev[2], st);   // ev[1]..ev[2] brackets the dominant kernel alone
-    if (!force_generic && !a.ref_mode) hipLaunchKernelGGL(k_dp_long, dim3(kLongBlocks), dim3(256), 0, st, a);
+    if (!force_generic && !a.ref_mode)
+        hipLaunchKernelGGL(k_dp_long, dim3(predicted_blocks(c->hist_long, kLongBlocks)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dp_generic, dim3(256), dim3(256), 0, st, a);
 }
 
@@ -507,6 +525,23 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         for (int k = 0; k < kNumBandClasses; ++k) stats->n_band_reads += c->h_counters[kCntClass0 + kBandClass0 + k];
         stats->n_band_fallback = c->h_counters[kCntBandFallback];
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
+    }
+    {   // queue lengths of this call, for the grids of the next one (enqueue_scoring)
+        int exact_chunks = 0, wide_chunks = 0;
+        for (int k = 0; k < kNumClasses; ++k) {
+            const int per = 64 / class_G(k);
+            exact_chunks += (c->h_counters[kCntClass0 + k] + per - 1) / per;
+        }
+        for (int k = 2; k < kNumBandClasses; ++k) {
+            const int per = 64 / band_class_G(k);
+            wide_chunks += (c->h_counters[kCntClass0 + kBandClass0 + k] + per - 1) / per;
+        }
+        c->hist_valid = true;
+        c->hist_band_mode = c->p_args.band_mode;
+        c->hist_reads = std::max(1, b->n_reads);
+        c->hist_exact_chunks = exact_chunks;
+        c->hist_wide_chunks = wide_chunks;
+        c->hist_long = c->h_counters[kCntClass0 + kLongClass];
     }
     {   // adaptive: noisy reads mostly fail the certificate and pay for both passes
         int nb = 0;

@@ -1146,13 +1146,17 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
             a.table[a.tab_off[r] + k] = sc;
         }
     }
+    // the bounds of all candidates at once, one per lane (the search below runs on one lane and would otherwise
+    // evaluate band_ub once per window entry); b0col is free after the forward pass
+    int* const ubA = reinterpret_cast<int*>(b0col);
+    if (run)
+        for (int k = lig; k < n; k += G) ubA[k] = band_ub(geo, nfl, ntr, nfr, m, lo + k, a.end_flags);
     wave_lds_sync();
     if (act && first) {
         bool certified = false;
         if (run) {
             SeenMask64 seen;
-            const int flags = a.end_flags;
-            auto ub = [&](int k) { return band_ub(geo, nfl, ntr, nfr, m, lo + k, flags); };
+            auto ub = [&](int k) { return ubA[k]; };
             const CertResult cr = search_replay_cert(a.est_cn[r], a.step, a.lsr, a.max_iters, a.tie_last, comb, lo, n, seen, ub);
             if (!cr.uncertain) {
                 certified = true;

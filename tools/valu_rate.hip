@@ -26,6 +26,10 @@ __global__ void __launch_bounds__(256) k(int* out, int iters, int a0) {
         if (KIND == 11) { REP64(asm volatile("v_cvt_f32_ubyte1 %0, %1\n v_cvt_f32_ubyte2 %2, %3\n v_cvt_f32_ubyte0 %4, %5\n v_cvt_f32_ubyte3 %6, %7" : "+v"(fa), "+v"(b), "+v"(fc), "+v"(d), "+v"(fe), "+v"(f), "+v"(fg), "+v"(h));) }
         if (KIND == 12) { REP64(asm volatile("v_pk_max_i16 %0, %0, %1\n v_pk_add_i16 %2, %2, %3\n v_pk_max_i16 %4, %4, %5\n v_pk_add_i16 %6, %6, %7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));) }
         if (KIND == 13) { REP64(asm volatile("v_add3_u32 %0, %0, %1, %2\n v_add3_u32 %2, %2, %3, %4\n v_add3_u32 %4, %4, %5, %6\n v_add3_u32 %6, %6, %7, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));) }
+        // dependency distance 1 (every instruction needs the previous result) and 2
+        if (KIND == 14) { REP64(asm volatile("v_max3_i32 %0, %0, %1, %2\n v_max3_i32 %0, %0, %3, %4\n v_max3_i32 %0, %0, %5, %6\n v_max3_i32 %0, %0, %7, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));) }
+        if (KIND == 15) { REP64(asm volatile("v_max3_i32 %0, %0, %1, %2\n v_add_u32 %3, %3, %4\n v_max3_i32 %0, %0, %5, %6\n v_add_u32 %7, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));) }
+        if (KIND == 16) { REP64(asm volatile("v_max_i32 %0, %0, %1\n v_max_i32 %0, %0, %3\n v_max_i32 %0, %0, %5\n v_max_i32 %0, %0, %7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));) }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d + e + f + g + h + (int)(fa + fb + fc + fd + fe + ff + fg + fh);
 }
@@ -69,5 +73,8 @@ int main() {
     run<10>("v_mov_b32_dpp", d_out);
     run<11>("v_cvt_f32_ubyteN", d_out);
     run<13>("v_add3_u32", d_out);
+    run<14>("max3 chain dist 1", d_out);
+    run<15>("max3 chain dist 2", d_out);
+    run<16>("max chain dist 1", d_out);
     return 0;
 }
