@@ -70,7 +70,8 @@ def load(build: bool = True):
         # Callers that keep several batched calls in flight (one context + stream each) need a
         # hardware queue per stream; the HIP runtime's default is 4 for the whole process.  Read at HIP initialisation.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-        path = _build.LIB_PATH
+        path = os.environ.get("STRKIT_AMD_LIB", _build.LIB_PATH)   # a privately built copy (profiling aids in tools/)
+        build = build and path == _build.LIB_PATH
         if build and _build.stale():
             try:
                 _build.build()

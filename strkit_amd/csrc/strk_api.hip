@@ -526,6 +526,10 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         stats->n_band_fallback = c->h_counters[kCntBandFallback];
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
     }
+#ifdef STRK_PHASE_TIMING
+    fprintf(stderr, "[phase ticks/64] header %d stage %d tables %d bwd %d fwd %d epilogue %d\n", c->h_counters[40], c->h_counters[41],
+            c->h_counters[42], c->h_counters[43], c->h_counters[44], c->h_counters[45]);
+#endif
     {   // queue lengths of this call, for the grids of the next one (enqueue_scoring)
         int exact_chunks = 0, wide_chunks = 0;
         for (int k = 0; k < kNumClasses; ++k) {

@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     if (threadIdx.x == 0) { s_cells = 0; s_bytes_band = 0; s_bytes_exact = 0; }
     __syncthreads();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    int r = 0, nfl = 0, ntr = 0, nfr = 0, m = 1, lo = 0, n = 0;
+    int r = 0, l = 0, nfl = 0, ntr = 0, nfr = 0, m = 1, lo = 0, n = 0;
     if (gid < n_items) {
         r = items ? items[gid] : gid;
         // locus of read r: last l with read_off[l] <= r
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
             const int mid = (lo_l + hi_l) >> 1;
             if (a.read_off[mid] <= r) lo_l = mid; else hi_l = mid;
         }
-        const int l = lo_l;
+        l = lo_l;
         a.read_locus[r] = l;
         m = a.motif_off[l + 1] - a.motif_off[l];
         nfl = a.nfl[r]; ntr = a.ntr[r]; nfr = a.nfr[r];
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
         const int idx = s_base[c] + atomicAdd(&s_cnt[c], 1);
         if (idx < a.list_stride) {
             a.cls_list[(size_t)c * a.list_stride * 2 + 2 * idx] = r;
-            a.cls_list[(size_t)c * a.list_stride * 2 + 2 * idx + 1] = k0;
+            a.cls_list[(size_t)c * a.list_stride * 2 + 2 * idx + 1] = band_list >= 0 ? l : k0;   // band items: the locus (k0 is 0)
         } else {
             atomicOr(&a.counters[kCntError], kErrScratch);
         }
@@ -998,6 +998,19 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
 #undef STRK_BAND_STEP
 }
 
+// Profiling aid (tools/phase_timing.sh builds a private copy of the library with -DSTRK_PHASE_TIMING): shader-clock
+// ticks per phase of band_wave, summed over waves into the spare counter slots 40..47.
+#ifdef STRK_PHASE_TIMING
+#define STRK_PHASE(i)                                                                                  \
+    do {                                                                                               \
+        const unsigned long long t_ = __builtin_readcyclecounter();                                    \
+        if (lane == 0) atomicAdd(&a.counters[40 + (i)], (int)((t_ - tphase) >> 6));                    \
+        tphase = t_;                                                                                   \
+    } while (0)
+#else
+#define STRK_PHASE(i) do { } while (0)
+#endif
+
 // Processes 64/G items of band class BC (G = 8 << BC lanes per read), one per group.
 template <int BC>
 __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw, const uint8_t* s_enc, const int8_t* s_mat) {
@@ -1006,6 +1019,9 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
     constexpr BandLayout lay(BC);
     const int cls = kBandClass0 + BC;
     const int lane = threadIdx.x & 63;
+#ifdef STRK_PHASE_TIMING
+    unsigned long long tphase = __builtin_readcyclecounter();
+#endif
     const int lig = lane & (G - 1);
     const int grp = lane / G;
     const bool first = lig == 0, last = lig == G - 1;
@@ -1028,14 +1044,16 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
     long long soff = 0;
     const uint8_t* motif = a.motifs;
     if (act) {
-        r = list[2 * it];
+        const int2 item = reinterpret_cast<const int2*>(list)[it];   // (read, locus): two levels of dependent loads, not three
+        r = item.x;
+        const int l = item.y;
+        const int mo0 = a.motif_off[l], mo1 = a.motif_off[l + 1];
         nfl = a.nfl[r]; ntr = a.ntr[r]; nfr = a.nfr[r];
         soff = a.seq_off[r];
-        const int l = a.read_locus[r];
-        motif += a.motif_off[l];
-        m = a.motif_off[l + 1] - a.motif_off[l];
         lo = a.win_lo[r];
         n = a.win_n[r];
+        motif += mo0;
+        m = mo1 - mo0;
     }
     const int ndb = nfl + ntr + nfr;
     const BandGeo geo = band_geometry(nfl, ntr, nfr, m, lo, max(n, 1));
@@ -1043,31 +1061,54 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
     const int rowsT = act ? nfr : 0;
     const bool dbBeg = a.end_flags & 1, dbEnd = a.end_flags & 2, cBeg = a.end_flags & 4, cEnd = a.end_flags & 8;
 
+    STRK_PHASE(0);
     // ---- stage: class-byte array with pads, symbol set, row words, row symbols ------------------
     if (first) misc[0] = 0;
     wave_lds_sync();
     {
+        // window bytes -> symbols, a dword per lane and eight dwords in flight (the loop is bound by load latency);
+        // slots outside the window get 0xff
         unsigned mask = 0;
         const uint8_t* seq = a.seqs + soff;
-        for (int s0 = lig; s0 < lay.sel_len; s0 += 4 * G) {
-            int raw[4];
+        constexpr int ND = lay.sel_len / 4;
+        unsigned* const selw = reinterpret_cast<unsigned*>(selb);
+        for (int d0 = lig; d0 < ND; d0 += 8 * G) {
+            unsigned w[8], ok[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = s0 + u * G - lay.pad;
-                raw[u] = (act && j >= 0 && j < ndb) ? (int)seq[j] : -1;
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + u * G, j0 = 4 * d - lay.pad;
+                unsigned v = 0, o = 0;
+                if (act && d < ND && j0 + 3 >= 0 && j0 < ndb) {
+                    if (j0 >= 0 && j0 + 3 < ndb) {
+                        __builtin_memcpy(&v, seq + j0, 4);   // unaligned dword load
+                        o = 0xfu;
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            if (j0 + b >= 0 && j0 + b < ndb) { v |= (unsigned)seq[j0 + b] << (8 * b); o |= 1u << b; }
+                    }
+                }
+                w[u] = v;
+                ok[u] = o;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = s0 + u * G;
-                int sym = 0xff;
-                if (raw[u] >= 0) { sym = s_enc[raw[u]]; mask |= 1u << sym; }
-                if (s < lay.sel_len) selb[s] = (uint8_t)sym;
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + u * G;
+                unsigned out = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    unsigned sym = 0xffu;
+                    if ((ok[u] >> b) & 1u) { sym = s_enc[(w[u] >> (8 * b)) & 0xffu]; mask |= 1u << sym; }
+                    out |= sym << (8 * b);
+                }
+                if (d < ND) selw[d] = out;
             }
         }
         if (mask) atomicOr(reinterpret_cast<unsigned*>(&misc[0]), mask);
         for (int k = lig; k < m; k += G) motifL[k] = act ? s_enc[motif[k]] : (uint8_t)kNullSym;
     }
     wave_lds_sync();
+    STRK_PHASE(1);
     const unsigned symmask = (unsigned)misc[0];
     bool fallback = act && __popc(symmask) > 8;   // more symbol classes than a v_perm word holds: exact path decides
     for (int e = lig; e < 18; e += G) {
@@ -1125,6 +1166,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
     }
     for (int k = lig; k < lay.maxcol; k += G) b0col[k] = (short)kBandNeg16;
     wave_lds_sync();
+    STRK_PHASE(2);
 
     BandCtx x;
     x.lig = lig; x.first = first; x.last = last; x.tbl = tbl; x.selb = selb;
@@ -1135,8 +1177,10 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
     // backward pass (reversed right flank x reversed window), then forward pass with the fork rows
     band_pass<G, true, false>(x, ct, run ? rowsT : 0, geo.bdlo, dbEnd, cEnd, 0, 0, 1, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
+    STRK_PHASE(3);
     band_pass<G, false, FLY>(x, cp, run ? rowsP : 0, geo.dlo, dbBeg, cBeg, nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
+    STRK_PHASE(4);
     if (run) {
         for (int k = lig; k < n; k += G) {
             const int R = nfl + (lo + k) * m;
@@ -1181,6 +1225,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
         }
     }
     wave_lds_sync();
+    STRK_PHASE(5);
 }
 
 // Two kernels so that the common short classes (0, 1) are not register-allocated together with the

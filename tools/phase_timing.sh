@@ -1,0 +1,15 @@
+#!/bin/bash
+# Where k_dp_band spends its time: builds a private copy of the library with -DSTRK_PHASE_TIMING and runs a few
+# calls of the bench workload (run on the GPU box from the repo root).
+set -e
+mkdir -p gpurun_out
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-unused-parameter -DSTRK_PHASE_TIMING \
+  -o gpurun_out/libstrkit_amd_phase.so strkit_amd/csrc/strk_api.hip
+STRKIT_AMD_LIB=$PWD/gpurun_out/libstrkit_amd_phase.so python3 - <<'PY'
+import sys; sys.path.insert(0, ".")
+from strkit_amd.synth import make_config
+from strkit_amd.batch import count_loci
+b = make_config(2)
+for _ in range(3):
+    count_loci(b)
+PY
