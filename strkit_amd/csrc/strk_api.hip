@@ -94,6 +94,7 @@ struct strk_ctx {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // call start, exact DP start/end, call end, band start/end
     size_t scratch_ints = 0;
     int band_cooldown = 0;   // > 0: the band kernel is switched off for that many calls (too many certificates failed)
+    int band_penalty = 32;   // length of the next cool-down (doubles while retries keep failing)
     // work-queue lengths of the previous finished call (wave chunks), used to size the persistent grids of the
     // kernels that usually have little or nothing to do: an idle block still claims its 70-80 KB of LDS on a CU
     // and so delays the band blocks of the calls it overlaps with
@@ -277,35 +278,79 @@ int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs
     HIP_TRY(hipMemcpy(need_hi.data(), rp.need_hi, (size_t)nl * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(frac.data(), rp.frac, (size_t)nl * 8, hipMemcpyDeviceToHost));
 
+    // Few loci with misses (the usual case): fetch only their slices.  Many (noisy reads whose banded tables cannot
+    // be certified from a different start): one bulk copy per array is cheaper than thirteen small ones per locus.
+    int n_pending = 0;
+    for (int l = 0; l < nl; ++l) n_pending += next_read[l] < read_off[l + 1];
+    const bool bulk = n_pending > 24;
+    const size_t nr = (size_t)b->n_reads;
+    std::vector<int32_t> m_est, m_win_lo, m_win_n, m_rep, m_nfl, m_ntr, m_nfr, m_cn, m_score, m_n, m_start, m_table;
+    std::vector<int64_t> m_tab_off;
+    std::vector<uint8_t> m_exact;
+    if (bulk) {
+        auto all32 = [&](std::vector<int32_t>& v, const int32_t* src, size_t cnt) {
+            v.resize(cnt);
+            return hipMemcpy(v.data(), src, cnt * 4, hipMemcpyDeviceToHost);
+        };
+        HIP_TRY(all32(m_est, b->est_cn, nr));
+        HIP_TRY(all32(m_win_lo, a.win_lo, nr));
+        HIP_TRY(all32(m_win_n, a.win_n, nr));
+        HIP_TRY(all32(m_rep, a.rep, nr));
+        HIP_TRY(all32(m_nfl, b->nfl, nr));
+        HIP_TRY(all32(m_ntr, b->ntr, nr));
+        HIP_TRY(all32(m_nfr, b->nfr, nr));
+        HIP_TRY(all32(m_cn, rp.out_cn, nr));
+        HIP_TRY(all32(m_score, rp.out_score, nr));
+        HIP_TRY(all32(m_n, rp.out_n, nr));
+        HIP_TRY(all32(m_start, rp.out_start, nr));
+        HIP_TRY(all32(m_table, a.table, nr * ts));
+        m_tab_off.resize(nr);
+        HIP_TRY(hipMemcpy(m_tab_off.data(), a.tab_off, nr * 8, hipMemcpyDeviceToHost));
+        if (a.band_mode) {
+            m_exact.resize(nr);
+            HIP_TRY(hipMemcpy(m_exact.data(), a.exact, nr, hipMemcpyDeviceToHost));
+        }
+    }
     std::vector<MissLocus> loci;
+    loci.reserve((size_t)n_pending);
     for (int l = 0; l < nl; ++l) {
         if (next_read[l] >= read_off[l + 1]) continue;
         MissLocus L;
         L.l = l; L.r0 = read_off[l]; L.r1 = read_off[l + 1]; L.m = motif_off[l + 1] - motif_off[l];
         L.first = next_read[l]; L.frac = frac[l]; L.need_lo = need_lo[l]; L.need_hi = need_hi[l];
         const size_t n = (size_t)(L.r1 - L.r0);
-        auto get32 = [&](std::vector<int32_t>& v, const int32_t* src) {
+        auto get32 = [&](std::vector<int32_t>& v, const int32_t* src, const std::vector<int32_t>& mirror) {
+            if (bulk) {
+                v.assign(mirror.begin() + L.r0, mirror.begin() + L.r1);
+                return hipSuccess;
+            }
             v.resize(n);
             return hipMemcpy(v.data(), src + L.r0, n * 4, hipMemcpyDeviceToHost);
         };
-        HIP_TRY(get32(L.est, b->est_cn));
-        HIP_TRY(get32(L.win_lo, a.win_lo));
-        HIP_TRY(get32(L.win_n, a.win_n));
-        HIP_TRY(get32(L.rep, a.rep));
-        HIP_TRY(get32(L.nfl, b->nfl));
-        HIP_TRY(get32(L.ntr, b->ntr));
-        HIP_TRY(get32(L.nfr, b->nfr));
-        HIP_TRY(get32(L.o_cn, rp.out_cn));
-        HIP_TRY(get32(L.o_score, rp.out_score));
-        HIP_TRY(get32(L.o_n, rp.out_n));
-        HIP_TRY(get32(L.o_start, rp.out_start));
-        L.tab_off.resize(n);
-        HIP_TRY(hipMemcpy(L.tab_off.data(), a.tab_off + L.r0, n * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(get32(L.est, b->est_cn, m_est));
+        HIP_TRY(get32(L.win_lo, a.win_lo, m_win_lo));
+        HIP_TRY(get32(L.win_n, a.win_n, m_win_n));
+        HIP_TRY(get32(L.rep, a.rep, m_rep));
+        HIP_TRY(get32(L.nfl, b->nfl, m_nfl));
+        HIP_TRY(get32(L.ntr, b->ntr, m_ntr));
+        HIP_TRY(get32(L.nfr, b->nfr, m_nfr));
+        HIP_TRY(get32(L.o_cn, rp.out_cn, m_cn));
+        HIP_TRY(get32(L.o_score, rp.out_score, m_score));
+        HIP_TRY(get32(L.o_n, rp.out_n, m_n));
+        HIP_TRY(get32(L.o_start, rp.out_start, m_start));
         L.exact.assign(n, 1);
-        if (a.band_mode) HIP_TRY(hipMemcpy(L.exact.data(), a.exact + L.r0, n, hipMemcpyDeviceToHost));
         // copies of a read share the table slot of their first occurrence, which lies in the same locus
-        L.table.resize(n * ts);
-        HIP_TRY(hipMemcpy(L.table.data(), a.table + (size_t)L.r0 * ts, n * ts * 4, hipMemcpyDeviceToHost));
+        if (bulk) {
+            L.tab_off.assign(m_tab_off.begin() + L.r0, m_tab_off.begin() + L.r1);
+            if (a.band_mode) L.exact.assign(m_exact.begin() + L.r0, m_exact.begin() + L.r1);
+            L.table.assign(m_table.begin() + (size_t)L.r0 * ts, m_table.begin() + (size_t)L.r1 * ts);
+        } else {
+            L.tab_off.resize(n);
+            HIP_TRY(hipMemcpy(L.tab_off.data(), a.tab_off + L.r0, n * 8, hipMemcpyDeviceToHost));
+            if (a.band_mode) HIP_TRY(hipMemcpy(L.exact.data(), a.exact + L.r0, n, hipMemcpyDeviceToHost));
+            L.table.resize(n * ts);
+            HIP_TRY(hipMemcpy(L.table.data(), a.table + (size_t)L.r0 * ts, n * ts * 4, hipMemcpyDeviceToHost));
+        }
         L.ext.resize(n);
         L.ext_lo.assign(n, 0);
         loci.push_back(std::move(L));
@@ -343,11 +388,28 @@ int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs
         if ((rc = c->table2.ensure(tab2 * 4))) return rc;
         if ((rc = c->items.ensure(items.size() * 4))) return rc;
         if ((rc = c->cls_list.ensure((size_t)kNumLists * n_chunks * 2 * 4))) return rc;
-        for (size_t i = 0; i < items.size(); ++i) {
-            const size_t r = (size_t)items[i];
-            HIP_TRY(hipMemcpyAsync(c->win_lo2.as<int32_t>() + r, &w_lo[i], 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(c->win_n2.as<int32_t>() + r, &w_n[i], 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(c->tab_off2.as<int64_t>() + r, &w_off[i], 8, hipMemcpyHostToDevice, st));
+        std::vector<int32_t> f_lo, f_n;   // full-size images when many reads are re-scored (must outlive the copies)
+        std::vector<int64_t> f_off;
+        if (items.size() > 48) {
+            f_lo.assign(nr, 0);
+            f_n.assign(nr, 0);
+            f_off.assign(nr, 0);
+            for (size_t i = 0; i < items.size(); ++i) {
+                const size_t r = (size_t)items[i];
+                f_lo[r] = w_lo[i];
+                f_n[r] = w_n[i];
+                f_off[r] = w_off[i];
+            }
+            HIP_TRY(hipMemcpyAsync(c->win_lo2.p, f_lo.data(), nr * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c->win_n2.p, f_n.data(), nr * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c->tab_off2.p, f_off.data(), nr * 8, hipMemcpyHostToDevice, st));
+        } else {
+            for (size_t i = 0; i < items.size(); ++i) {
+                const size_t r = (size_t)items[i];
+                HIP_TRY(hipMemcpyAsync(c->win_lo2.as<int32_t>() + r, &w_lo[i], 4, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(c->win_n2.as<int32_t>() + r, &w_n[i], 4, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(c->tab_off2.as<int64_t>() + r, &w_off[i], 8, hipMemcpyHostToDevice, st));
+            }
         }
         HIP_TRY(hipMemcpyAsync(c->items.p, items.data(), items.size() * 4, hipMemcpyHostToDevice, st));
         KArgs a2 = a;
@@ -432,12 +494,25 @@ int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs
         }
         pending.swap(still);
     }
-    for (auto& L : loci) {   // write back the reads the host finished
-        const size_t n = (size_t)(L.r1 - L.r0);
-        HIP_TRY(hipMemcpyAsync(rp.out_cn + L.r0, L.o_cn.data(), n * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(rp.out_score + L.r0, L.o_score.data(), n * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(rp.out_n + L.r0, L.o_n.data(), n * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(rp.out_start + L.r0, L.o_start.data(), n * 4, hipMemcpyHostToDevice, st));
+    if (bulk) {   // write back through the full-size images
+        for (auto& L : loci) {
+            std::copy(L.o_cn.begin(), L.o_cn.end(), m_cn.begin() + L.r0);
+            std::copy(L.o_score.begin(), L.o_score.end(), m_score.begin() + L.r0);
+            std::copy(L.o_n.begin(), L.o_n.end(), m_n.begin() + L.r0);
+            std::copy(L.o_start.begin(), L.o_start.end(), m_start.begin() + L.r0);
+        }
+        HIP_TRY(hipMemcpyAsync(rp.out_cn, m_cn.data(), nr * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(rp.out_score, m_score.data(), nr * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(rp.out_n, m_n.data(), nr * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(rp.out_start, m_start.data(), nr * 4, hipMemcpyHostToDevice, st));
+    } else {
+        for (auto& L : loci) {   // write back the reads the host finished
+            const size_t n = (size_t)(L.r1 - L.r0);
+            HIP_TRY(hipMemcpyAsync(rp.out_cn + L.r0, L.o_cn.data(), n * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(rp.out_score + L.r0, L.o_score.data(), n * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(rp.out_n + L.r0, L.o_n.data(), n * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(rp.out_start + L.r0, L.o_start.data(), n * 4, hipMemcpyHostToDevice, st));
+        }
     }
     HIP_TRY(hipStreamSynchronize(st));
     if (stats) {
@@ -550,8 +625,18 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
     {   // adaptive: noisy reads mostly fail the certificate and pay for both passes
         int nb = 0;
         for (int k = 0; k < kNumBandClasses; ++k) nb += c->h_counters[kCntClass0 + kBandClass0 + k];
-        if (c->band_cooldown > 0) --c->band_cooldown;
-        else if (nb >= 64 && 2 * c->h_counters[kCntBandFallback] > nb) c->band_cooldown = 32;
+        if (c->band_cooldown > 0) {
+            --c->band_cooldown;
+        } else if (nb >= 64) {
+            // more than half of the band reads fell back: switch the band off for a while, and for twice as long
+            // every time a retry fails again (a failed retry costs a full extra pass plus host rounds)
+            if (2 * c->h_counters[kCntBandFallback] > nb) {
+                c->band_cooldown = c->band_penalty;
+                c->band_penalty = std::min(c->band_penalty * 2, 1 << 14);
+            } else {
+                c->band_penalty = 32;
+            }
+        }
     }
     const int err = c->h_counters[kCntError];
     int rc;
