@@ -17,6 +17,7 @@
  *   strk_ref_repeat_count    get_ref_repeat_count() incl. score_ref_boundaries(), once per locus
  *                            — strkit/call/repeats.py:23-43,73-192 (parasail sg_qe_scan_profile_sat);
  *                            strk_score_ref_table is its scoring primitive
+ *   strk_ref_repeat_count_batch  the same for every locus of a block (call_locus.py:796-810 once per locus)
  *   strk_realign             the parasail sg_dx_trace_scan_16 call + CIGAR of realign_read()
  *                            — strkit/call/realign.py:56-72 (gate at realign.py:65, caller call_locus.py:867-901)
  *   strk_score_table         one parasail semi-global alignment score per candidate copy number
@@ -173,6 +174,17 @@ int strk_ref_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr,
                           const uint8_t* motif, int32_t motif_len, int32_t ref_size,
                           int32_t vcf_anchor_size, int32_t max_iters, int32_t local_search_range,
                           int32_t step_size, int32_t respect_coords, int32_t* out9);
+
+/* strk_ref_repeat_count for a block of loci in lock-step: every round of boundary-extension scoring is one device
+ * call for all loci that still need scores, the final counts one call per distinct search schedule.  Locus i owns
+ * seqs[seq_off[i] .. seq_off[i+1]) laid out fl|tr|fr and motifs[motif_off[i] .. motif_off[i+1]); max_iters /
+ * local_search_range / step_size are per locus (get_reference_rc_params, repeat_count_params.py:17-42, depends on
+ * the estimate).  out9 is [n_loci * 9], fields as strk_ref_repeat_count.  HOST buffers. */
+int strk_ref_repeat_count_batch(strk_ctx* ctx, int32_t n_loci, const int32_t* start_count, const uint8_t* seqs,
+                                const int64_t* seq_off, const int32_t* nfl, const int32_t* ntr, const int32_t* nfr,
+                                const uint8_t* motifs, const int32_t* motif_off, const int32_t* ref_size,
+                                int32_t vcf_anchor_size, const int32_t* max_iters, const int32_t* local_search_range,
+                                const int32_t* step_size, int32_t respect_coords, int32_t* out9);
 
 /* Batched drop-in for the parasail call of realign_read (strkit/call/realign.py:56-63,71):
  * sg_dx_trace_scan_16(s1 = reference window, s2 = wildcarded read, open, extend, dna_matrix) — s1 aligned end

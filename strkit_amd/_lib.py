@@ -46,7 +46,7 @@ class StrkStats(C.Structure):
 # Every symbol include/strkit_amd.h declares (tests check the .so exports exactly these).
 EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_repeat_count", "strk_count_loci",
            "strk_count_loci_device", "strk_submit_loci_device", "strk_finish", "strk_score_table",
-           "strk_score_ref_table", "strk_ref_repeat_count", "strk_realign")
+           "strk_score_ref_table", "strk_ref_repeat_count", "strk_ref_repeat_count_batch", "strk_realign")
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -110,6 +110,9 @@ def load(build: bool = True):
         L.strk_ref_repeat_count.restype = C.c_int
         L.strk_ref_repeat_count.argtypes = ([C.c_void_p, C.c_int32] + [C.c_char_p, C.c_int32] * 4 + [C.c_int32] * 6
                                             + [_i32p])
+        L.strk_ref_repeat_count_batch.restype = C.c_int
+        L.strk_ref_repeat_count_batch.argtypes = ([C.c_void_p, C.c_int32] + [C.c_void_p] * 9 + [C.c_int32] + [C.c_void_p] * 3
+                                                  + [C.c_int32, C.c_void_p])
         L.strk_realign.restype = C.c_int
         L.strk_realign.argtypes = ([C.c_void_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p] * 5
                                    + [C.POINTER(StrkStats)])

@@ -766,142 +766,241 @@ int score_table_impl(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, 
 // Lazily scored (fwd score, fwd end_query, rev score, rev end_query) per candidate size for one locus:
 // two device "reads" — the window itself and its reversal with the flanks swapped
 // (repeats.py:32-41: ext_l_seq = (tr_candidate + flank_right_seq)[::-1] against db_seq[::-1]).
-struct RefScorer {
-    strk_ctx* ctx;
-    std::vector<uint8_t> seqs, motifs;
-    int64_t seq_off[3];
-    int32_t nfl[2], ntr[2], nfr[2], read_off[3], motif_off[3];
-    int32_t step;
-    std::vector<int64_t> sizes;                 // cached sizes (unordered)
-    std::vector<std::array<int32_t, 4>> vals;   // fs, fe, rs, re
+// One locus of the reference-side path (get_ref_repeat_count, strkit/call/repeats.py:73-192).  The search runs on
+// the host over (score, end_query) pairs the device computes; a job whose search meets a size that has not been
+// scored yet reports the window it needs and is re-run from the start once the batch of all such windows is back.
+struct RefJob {
+    int32_t start = 0, nfl = 0, ntr = 0, nfr = 0, m = 1, ref_size = 0, max_iters = 0, lsr = 0, step = 1;
+    std::vector<uint8_t> db, motif;             // fl|tr|fr and the motif, as given
+    std::vector<int64_t> sizes;                 // scored sizes (unordered)
+    std::vector<std::array<int32_t, 4>> vals;   // fwd score, fwd end_query, rev score, rev end_query
+    int32_t l_offset = 0, r_offset = 0, n_off = 0;
+    int64_t need_lo = 0, need_hi = -1;
     int find(int64_t i) const {
         for (size_t k = 0; k < sizes.size(); ++k)
             if (sizes[k] == i) return (int)k;
         return -1;
     }
-    int ensure(int64_t w_lo, int64_t w_hi) {  // make every size in [w_lo, w_hi] available
-        bool all = true;
-        for (int64_t i = w_lo; i <= w_hi && all; ++i) all = find(i) >= 0;
-        if (all) return 0;
-        const int64_t pad = step == 1 ? 8 : 0;   // dense look-ahead only pays for unit steps
-        int64_t lo = std::max<int64_t>(0, w_lo - pad), hi = w_hi + pad;
-        if (hi - lo + 1 > 4096) return fail(STRK_E_INVALID, "reference-side window too wide");
-        const int32_t n = (int32_t)(hi - lo + 1);
-        const int32_t los[2] = {(int32_t)lo, (int32_t)lo}, ns[2] = {n, n};
-        const int64_t toff[3] = {0, n, 2 * (int64_t)n};
-        std::vector<int32_t> sc(2 * (size_t)n), eq(2 * (size_t)n);
-        strk_batch b;
-        b.n_reads = 2; b.n_loci = 2;
-        b.seqs = seqs.data(); b.seq_off = seq_off; b.nfl = nfl; b.ntr = ntr; b.nfr = nfr; b.est_cn = nullptr;
-        b.read_off = read_off; b.motifs = motifs.data(); b.motif_off = motif_off;
-        const int rc = score_table_impl(ctx, &b, los, ns, toff, STRK_DB_END_FREE, 0, 1, sc.data(), eq.data(), nullptr);
-        if (rc) return rc;
-        for (int32_t k = 0; k < n; ++k) {
-            if (find(lo + k) >= 0) continue;
-            sizes.push_back(lo + k);
-            vals.push_back({sc[k], eq[k], sc[n + k], eq[n + k]});
-        }
-        return 0;
+    bool has_all(int64_t w_lo, int64_t w_hi) const {
+        for (int64_t i = w_lo; i <= w_hi; ++i)
+            if (find(i) < 0) return false;
+        return true;
     }
 };
 
-// get_ref_repeat_count (strkit/call/repeats.py:73-192): boundary-extension search on the device-scored
-// (score, end_query) pairs, then the final read-style count on the adjusted flank/tract split.
+// Boundary-extension search of one job on its cached scores.  Returns 1 when finished (offsets set), 0 when it
+// needs sizes [need_lo, need_hi] scored first, < 0 on error.
+int ref_search(RefJob& j, int32_t vcf_anchor_size) {
+    const int32_t nfl = j.nfl, nfr = j.nfr, step = j.step, lsr = j.lsr;
+    // dicts in insertion order (repeats.py:103-104); fwd and rev are always filled together (:123-128)
+    std::vector<int64_t> key;
+    std::vector<int32_t> fs, fa, rs, ra;
+    auto find_key = [&](int64_t i) {
+        for (size_t k = 0; k < key.size(); ++k)
+            if (key[k] == i) return (int)k;
+        return -1;
+    };
+    int64_t st_size[4];
+    int32_t st_dir[4];
+    int sp = 0, n_off = 0;
+    st_size[sp] = (int64_t)j.start - step; st_dir[sp++] = -1;   // :100-101
+    st_size[sp] = (int64_t)j.start + step; st_dir[sp++] = 1;
+    st_size[sp] = j.start;                 st_dir[sp++] = 0;
+    const bool widen = step > lsr;
+    while (sp > 0 && n_off < j.max_iters) {                                  // :106
+        --sp;
+        const int64_t size = st_size[sp];
+        const int32_t dir = st_dir[sp];
+        if (size < 0) continue;                                              // :108-109
+        int64_t w_lo = size - ((dir < 1 || widen) ? lsr : 0);                // :114-117
+        if (w_lo < 0) w_lo = 0;
+        const int64_t w_hi = size + ((dir > -1 || widen) ? lsr : 0);
+        if (!j.has_all(w_lo, w_hi)) {
+            j.need_lo = w_lo;
+            j.need_hi = w_hi;
+            return 0;
+        }
+        for (int64_t i = w_lo; i <= w_hi; ++i) {                             // :119-130
+            if (find_key(i) >= 0) continue;
+            const auto& v = j.vals[(size_t)j.find(i)];
+            key.push_back(i);
+            fs.push_back(v[0]); fa.push_back(v[1] + 1 - nfl - j.ref_size);   // :34
+            rs.push_back(v[2]); ra.push_back(v[3] + 1 - nfr - j.ref_size);   // :41
+            ++n_off;
+        }
+        // mv = max((*fwd_scores, *rev_scores), key=(score, adj)): first maximum of the concatenation (:135)
+        bool have = false;
+        int64_t mv_i = 0;
+        int32_t mv_s = 0, mv_a = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int64_t i = w_lo; i <= w_hi; ++i) {
+                const int at = find_key(i);
+                const int32_t sc = pass == 0 ? fs[(size_t)at] : rs[(size_t)at];
+                const int32_t ad = pass == 0 ? fa[(size_t)at] : ra[(size_t)at];
+                if (!have || sc > mv_s || (sc == mv_s && ad > mv_a)) { have = true; mv_i = i; mv_s = sc; mv_a = ad; }
+            }
+        if (mv_i > size && find_key(mv_i + step) < 0 && mv_i + step >= 0) { st_size[sp] = mv_i + step; st_dir[sp++] = 1; }    // :136-143
+        if (mv_i < size && find_key(mv_i - step) < 0 && mv_i - step >= 0) { st_size[sp] = mv_i - step; st_dir[sp++] = -1; }  // :144-151
+    }
+    if (key.empty()) return fail(STRK_E_EMPTY, "max() arg is an empty sequence: no reference boundary could be scored");
+    size_t bf = 0, br = 0;                                                   // :154-156 first maxima by score
+    for (size_t k = 1; k < key.size(); ++k) {
+        if (fs[k] > fs[bf]) bf = k;
+        if (rs[k] > rs[br]) br = k;
+    }
+    j.l_offset = ra[br];                                                     // :161-162
+    j.r_offset = fa[bf];
+    if (j.l_offset >= nfl - vcf_anchor_size) j.l_offset = 0;                 // :164-169
+    if (j.r_offset >= nfr) j.r_offset = 0;
+    j.n_off = n_off;
+    return 1;
+}
+
+// Scores the requested windows of `req` jobs in ONE device call: two windows per job (the window and its
+// reversal with the flanks swapped, repeats.py:36-41), each against its own motif.
+int ref_score_requests(strk_ctx* ctx, std::vector<RefJob*>& req) {
+    const size_t nj = req.size();
+    std::vector<uint8_t> seqs, motifs;
+    std::vector<int64_t> seq_off{0}, toff{0};
+    std::vector<int32_t> nfl, ntr, nfr, read_off{0}, motif_off{0}, los, ns;
+    for (RefJob* j : req) {
+        const int64_t pad = j->step == 1 ? 8 : 0;   // dense look-ahead only pays for unit steps
+        const int64_t lo = std::max<int64_t>(0, j->need_lo - pad), hi = j->need_hi + pad;
+        if (hi - lo + 1 > 4096) return fail(STRK_E_INVALID, "reference-side window too wide");
+        const int32_t ndb = (int32_t)j->db.size();
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 0) {
+                seqs.insert(seqs.end(), j->db.begin(), j->db.end());
+                motifs.insert(motifs.end(), j->motif.begin(), j->motif.end());
+            } else {
+                seqs.insert(seqs.end(), j->db.rbegin(), j->db.rend());
+                motifs.insert(motifs.end(), j->motif.rbegin(), j->motif.rend());
+            }
+            seq_off.push_back(seq_off.back() + ndb);
+            nfl.push_back(pass == 0 ? j->nfl : j->nfr);   // reversed window: the right flank leads
+            ntr.push_back(j->ntr);
+            nfr.push_back(pass == 0 ? j->nfr : j->nfl);
+            read_off.push_back(read_off.back() + 1);
+            motif_off.push_back(motif_off.back() + j->m);
+            los.push_back((int32_t)lo);
+            ns.push_back((int32_t)(hi - lo + 1));
+            toff.push_back(toff.back() + (hi - lo + 1));
+        }
+    }
+    std::vector<int32_t> sc((size_t)toff.back()), eq((size_t)toff.back());
+    strk_batch b;
+    b.n_reads = (int32_t)(2 * nj); b.n_loci = (int32_t)(2 * nj);
+    b.seqs = seqs.data(); b.seq_off = seq_off.data(); b.nfl = nfl.data(); b.ntr = ntr.data(); b.nfr = nfr.data();
+    b.est_cn = nullptr; b.read_off = read_off.data(); b.motifs = motifs.data(); b.motif_off = motif_off.data();
+    const int rc = score_table_impl(ctx, &b, los.data(), ns.data(), toff.data(), STRK_DB_END_FREE, 0, 1, sc.data(), eq.data(), nullptr);
+    if (rc) return rc;
+    for (size_t q = 0; q < nj; ++q) {
+        RefJob* j = req[q];
+        const int32_t lo = los[2 * q], n = ns[2 * q];
+        const int64_t f0 = toff[2 * q], r0 = toff[2 * q + 1];
+        for (int32_t k = 0; k < n; ++k) {
+            if (j->find((int64_t)lo + k) >= 0) continue;
+            j->sizes.push_back((int64_t)lo + k);
+            j->vals.push_back({sc[(size_t)f0 + k], eq[(size_t)f0 + k], sc[(size_t)r0 + k], eq[(size_t)r0 + k]});
+        }
+    }
+    return 0;
+}
+
+// get_ref_repeat_count for a batch of loci: boundary-extension searches in lock-step rounds (one device call per
+// round for all loci that still need scores), then the final read-style counts of all loci in one call per
+// distinct search schedule.  out9[9*i ..] as strk_ref_repeat_count.
+int ref_repeat_count_batch_impl(strk_ctx* ctx, std::vector<RefJob>& jobs, int32_t vcf_anchor_size, int32_t respect_coords,
+                                int32_t* out9) {
+    if (!respect_coords) {
+        std::vector<RefJob*> pending;
+        for (auto& j : jobs) pending.push_back(&j);
+        for (int round = 0; !pending.empty(); ++round) {
+            if (round > 4096) return fail(STRK_E_DEVICE, "reference-side search did not converge");
+            std::vector<RefJob*> req;
+            for (RefJob* j : pending) {
+                const int r = ref_search(*j, vcf_anchor_size);
+                if (r < 0) return r;
+                if (r == 0) req.push_back(j);
+            }
+            if (req.empty()) break;
+            const int rc = ref_score_requests(ctx, req);
+            if (rc) return rc;
+            pending.swap(req);
+        }
+    }
+    // final counts on the adjusted flank / tract split (repeats.py:171-188), grouped by search schedule
+    const size_t nj = jobs.size();
+    std::vector<int32_t> nfl2(nj), ntr2(nj), nfr2(nj), start2(nj);
+    for (size_t i = 0; i < nj; ++i) {
+        const RefJob& j = jobs[i];
+        const int32_t lo_pos = j.l_offset > 0 ? j.l_offset : 0, ro_pos = j.r_offset > 0 ? j.r_offset : 0;   // :171-176
+        nfl2[i] = j.nfl - lo_pos; ntr2[i] = j.ntr + lo_pos + ro_pos; nfr2[i] = j.nfr - ro_pos;
+        if (nfl2[i] < 0 || nfr2[i] < 0) return fail(STRK_E_INVALID, "boundary offsets exceed the flanks");
+        // round(((start * motif_size) + max(0, l) + max(0, r)) / motif_size): true division, round-half-even (:182)
+        start2[i] = (int32_t)__builtin_rint((double)((int64_t)j.start * j.m + lo_pos + ro_pos) / (double)j.m);
+    }
+    std::vector<char> done(nj, 0);
+    for (size_t g = 0; g < nj; ++g) {
+        if (done[g]) continue;
+        std::vector<size_t> grp;
+        for (size_t i = g; i < nj; ++i)
+            if (!done[i] && jobs[i].max_iters == jobs[g].max_iters && jobs[i].lsr == jobs[g].lsr && jobs[i].step == jobs[g].step) {
+                grp.push_back(i);
+                done[i] = 1;
+            }
+        std::vector<uint8_t> seqs, motifs;
+        std::vector<int64_t> seq_off{0};
+        std::vector<int32_t> a_nfl, a_ntr, a_nfr, a_est, read_off{0}, motif_off{0};
+        for (size_t i : grp) {
+            seqs.insert(seqs.end(), jobs[i].db.begin(), jobs[i].db.end());
+            motifs.insert(motifs.end(), jobs[i].motif.begin(), jobs[i].motif.end());
+            seq_off.push_back(seq_off.back() + (int64_t)jobs[i].db.size());
+            a_nfl.push_back(nfl2[i]); a_ntr.push_back(ntr2[i]); a_nfr.push_back(nfr2[i]); a_est.push_back(start2[i]);
+            read_off.push_back(read_off.back() + 1);
+            motif_off.push_back(motif_off.back() + jobs[i].m);
+        }
+        strk_batch b;
+        b.n_reads = (int32_t)grp.size(); b.n_loci = (int32_t)grp.size();
+        b.seqs = seqs.data(); b.seq_off = seq_off.data(); b.nfl = a_nfl.data(); b.ntr = a_ntr.data(); b.nfr = a_nfr.data();
+        b.est_cn = a_est.data(); b.read_off = read_off.data(); b.motifs = motifs.data(); b.motif_off = motif_off.data();
+        strk_params p;
+        memset(&p, 0, sizeof p);
+        p.max_iters = jobs[g].max_iters; p.local_search_range = jobs[g].lsr; p.step_size = jobs[g].step;
+        p.tie_rule = STRK_TIE_FIRST; p.end_flags = STRK_SG_ALL; p.feedback = 0;
+        p.window = std::min(15, std::max(kDefaultWindow, jobs[g].lsr + jobs[g].step + 1));   // as strk_repeat_count
+        std::vector<int32_t> cn(grp.size()), sc(grp.size()), ni(grp.size());
+        const int rc = strk_count_loci(ctx, &b, &p, cn.data(), sc.data(), ni.data(), nullptr, nullptr);
+        if (rc) return rc;
+        for (size_t q = 0; q < grp.size(); ++q) {
+            const size_t i = grp[q];
+            int32_t* o = out9 + 9 * i;
+            o[0] = cn[q]; o[1] = sc[q]; o[2] = jobs[i].l_offset; o[3] = jobs[i].r_offset; o[4] = jobs[i].n_off; o[5] = ni[q];
+            o[6] = nfl2[i]; o[7] = ntr2[i]; o[8] = nfr2[i];
+        }
+    }
+    return 0;
+}
+
+void ref_job_init(RefJob& j, int32_t start, const uint8_t* tr, int32_t ntr, const uint8_t* fl, int32_t nfl, const uint8_t* fr,
+                  int32_t nfr, const uint8_t* motif, int32_t m, int32_t ref_size, int32_t max_iters, int32_t lsr, int32_t step) {
+    j.start = start; j.nfl = nfl; j.ntr = ntr; j.nfr = nfr; j.m = m; j.ref_size = ref_size;
+    j.max_iters = max_iters; j.lsr = lsr; j.step = step;
+    j.db.resize((size_t)nfl + ntr + nfr);
+    if (nfl) memcpy(j.db.data(), fl, (size_t)nfl);
+    if (ntr) memcpy(j.db.data() + nfl, tr, (size_t)ntr);
+    if (nfr) memcpy(j.db.data() + nfl + ntr, fr, (size_t)nfr);
+    j.motif.assign(motif, motif + m);
+}
+
+// get_ref_repeat_count (strkit/call/repeats.py:73-192) for one locus: a batch of one.
 int ref_repeat_count_impl(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int32_t ntr, const uint8_t* fl,
                           int32_t nfl, const uint8_t* fr, int32_t nfr, const uint8_t* motif, int32_t m, int32_t ref_size,
                           int32_t vcf_anchor_size, int32_t max_iters, int32_t lsr, int32_t step, int32_t respect_coords,
                           int32_t* out9) {
-    const int32_t ndb = nfl + ntr + nfr;
-    std::vector<uint8_t> db((size_t)ndb);
-    if (nfl) memcpy(db.data(), fl, (size_t)nfl);
-    if (ntr) memcpy(db.data() + nfl, tr, (size_t)ntr);
-    if (nfr) memcpy(db.data() + nfl + ntr, fr, (size_t)nfr);
-    int32_t l_offset = 0, r_offset = 0, n_off = 0;
-    if (!respect_coords) {
-        RefScorer sc;
-        sc.ctx = ctx;
-        sc.step = step;
-        sc.seqs.resize(2 * (size_t)ndb);
-        memcpy(sc.seqs.data(), db.data(), (size_t)ndb);
-        for (int32_t i = 0; i < ndb; ++i) sc.seqs[(size_t)ndb + i] = db[(size_t)ndb - 1 - i];
-        sc.motifs.resize(2 * (size_t)m);
-        for (int32_t i = 0; i < m; ++i) { sc.motifs[i] = motif[i]; sc.motifs[(size_t)m + i] = motif[m - 1 - i]; }
-        sc.seq_off[0] = 0; sc.seq_off[1] = ndb; sc.seq_off[2] = 2 * (int64_t)ndb;
-        sc.nfl[0] = nfl; sc.ntr[0] = ntr; sc.nfr[0] = nfr;
-        sc.nfl[1] = nfr; sc.ntr[1] = ntr; sc.nfr[1] = nfl;   // reversed window: the right flank leads
-        sc.read_off[0] = 0; sc.read_off[1] = 1; sc.read_off[2] = 2;
-        sc.motif_off[0] = 0; sc.motif_off[1] = m; sc.motif_off[2] = 2 * m;
-
-        // dicts in insertion order (repeats.py:103-104); fwd and rev are always filled together (:123-128)
-        std::vector<int64_t> key;
-        std::vector<int32_t> fs, fa, rs, ra;
-        auto find_key = [&](int64_t i) {
-            for (size_t k = 0; k < key.size(); ++k)
-                if (key[k] == i) return (int)k;
-            return -1;
-        };
-        int64_t st_size[4];
-        int32_t st_dir[4];
-        int sp = 0;
-        st_size[sp] = (int64_t)start_count - step; st_dir[sp++] = -1;   // :100-101
-        st_size[sp] = (int64_t)start_count + step; st_dir[sp++] = 1;
-        st_size[sp] = start_count;                 st_dir[sp++] = 0;
-        const bool widen = step > lsr;
-        while (sp > 0 && n_off < max_iters) {                                // :106
-            --sp;
-            const int64_t size = st_size[sp];
-            const int32_t dir = st_dir[sp];
-            if (size < 0) continue;                                          // :108-109
-            int64_t w_lo = size - ((dir < 1 || widen) ? lsr : 0);            // :114-117
-            if (w_lo < 0) w_lo = 0;
-            const int64_t w_hi = size + ((dir > -1 || widen) ? lsr : 0);
-            int rc = sc.ensure(w_lo, w_hi);
-            if (rc) return rc;
-            for (int64_t i = w_lo; i <= w_hi; ++i) {                         // :119-130
-                if (find_key(i) >= 0) continue;
-                const auto& v = sc.vals[(size_t)sc.find(i)];
-                key.push_back(i);
-                fs.push_back(v[0]); fa.push_back(v[1] + 1 - nfl - ref_size);   // :34
-                rs.push_back(v[2]); ra.push_back(v[3] + 1 - nfr - ref_size);   // :41
-                ++n_off;
-            }
-            // mv = max((*fwd_scores, *rev_scores), key=(score, adj)): first maximum of the concatenation (:135)
-            bool have = false;
-            int64_t mv_i = 0;
-            int32_t mv_s = 0, mv_a = 0;
-            for (int pass = 0; pass < 2; ++pass)
-                for (int64_t i = w_lo; i <= w_hi; ++i) {
-                    const int at = find_key(i);
-                    const int32_t s = pass == 0 ? fs[(size_t)at] : rs[(size_t)at];
-                    const int32_t ad = pass == 0 ? fa[(size_t)at] : ra[(size_t)at];
-                    if (!have || s > mv_s || (s == mv_s && ad > mv_a)) { have = true; mv_i = i; mv_s = s; mv_a = ad; }
-                }
-            if (mv_i > size && find_key(mv_i + step) < 0 && mv_i + step >= 0) { st_size[sp] = mv_i + step; st_dir[sp++] = 1; }    // :136-143
-            if (mv_i < size && find_key(mv_i - step) < 0 && mv_i - step >= 0) { st_size[sp] = mv_i - step; st_dir[sp++] = -1; }  // :144-151
-        }
-        if (key.empty()) return fail(STRK_E_EMPTY, "max() arg is an empty sequence: no reference boundary could be scored");
-        size_t bf = 0, br = 0;                                               // :154-156 first maxima by score
-        for (size_t k = 1; k < key.size(); ++k) {
-            if (fs[k] > fs[bf]) bf = k;
-            if (rs[k] > rs[br]) br = k;
-        }
-        l_offset = ra[br];                                                   // :161-162
-        r_offset = fa[bf];
-        if (l_offset >= nfl - vcf_anchor_size) l_offset = 0;                 // :164-169
-        if (r_offset >= nfr) r_offset = 0;
-    }
-    const int32_t lo_pos = l_offset > 0 ? l_offset : 0, ro_pos = r_offset > 0 ? r_offset : 0;   // :171-176
-    const int32_t nfl2 = nfl - lo_pos, ntr2 = ntr + lo_pos + ro_pos, nfr2 = nfr - ro_pos;
-    if (nfl2 < 0 || nfr2 < 0) return fail(STRK_E_INVALID, "boundary offsets exceed the flanks");
-    // round(((start * motif_size) + max(0, l) + max(0, r)) / motif_size): true division, round-half-even (:182)
-    const int32_t start2 = (int32_t)__builtin_rint((double)((int64_t)start_count * m + lo_pos + ro_pos) / (double)m);
-    int32_t cn = 0, score = 0, n_final = 0;
-    const int rc = strk_repeat_count(ctx, start2, db.data() + nfl2, ntr2, db.data(), nfl2, db.data() + nfl2 + ntr2, nfr2,
-                                     motif, m, max_iters, lsr, step, &cn, &score, &n_final);
-    if (rc) return rc;
-    out9[0] = cn; out9[1] = score; out9[2] = l_offset; out9[3] = r_offset; out9[4] = n_off; out9[5] = n_final;
-    out9[6] = nfl2; out9[7] = ntr2; out9[8] = nfr2;
-    return 0;
+    std::vector<RefJob> jobs(1);
+    ref_job_init(jobs[0], start_count, tr, ntr, fl, nfl, fr, nfr, motif, m, ref_size, max_iters, lsr, step);
+    return ref_repeat_count_batch_impl(ctx, jobs, vcf_anchor_size, respect_coords, out9);
 }
 
 
@@ -1245,6 +1344,30 @@ int strk_realign(strk_ctx* ctx, int32_t n_pairs, const uint8_t* s1, const int64_
     if (ctx->pending) return fail(STRK_E_INVALID, "a submitted call is pending on this context");
     return realign_impl(ctx, n_pairs, s1, s1_off, s2, s2_off, open, extend, gap_pref, out_score, out_end_ref, out_n_cigar,
                         cigar, cigar_off, stats);
+}
+
+int strk_ref_repeat_count_batch(strk_ctx* ctx, int32_t n_loci, const int32_t* start_count, const uint8_t* seqs,
+                                const int64_t* seq_off, const int32_t* nfl, const int32_t* ntr, const int32_t* nfr,
+                                const uint8_t* motifs, const int32_t* motif_off, const int32_t* ref_size,
+                                int32_t vcf_anchor_size, const int32_t* max_iters, const int32_t* local_search_range,
+                                const int32_t* step_size, int32_t respect_coords, int32_t* out9) {
+    if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
+    if (n_loci < 0) return fail(STRK_E_INVALID, "n_loci < 0");
+    if (n_loci == 0) return 0;
+    if (!start_count || !seqs || !seq_off || !nfl || !ntr || !nfr || !motifs || !motif_off || !ref_size || !max_iters ||
+        !local_search_range || !step_size || !out9)
+        return fail(STRK_E_INVALID, "NULL argument");
+    std::vector<RefJob> jobs((size_t)n_loci);
+    for (int32_t i = 0; i < n_loci; ++i) {
+        const int32_t m = motif_off[i + 1] - motif_off[i];
+        if (nfl[i] < 0 || ntr[i] < 0 || nfr[i] < 0 || m < 1 || seq_off[i + 1] - seq_off[i] != (int64_t)nfl[i] + ntr[i] + nfr[i])
+            return fail(STRK_E_INVALID, "locus %d: bad sequence lengths", i);
+        if (local_search_range[i] < 0 || step_size[i] < 1) return fail(STRK_E_INVALID, "locus %d: bad search schedule", i);
+        const uint8_t* s0 = seqs + seq_off[i];
+        ref_job_init(jobs[(size_t)i], start_count[i], s0 + nfl[i], ntr[i], s0, nfl[i], s0 + nfl[i] + ntr[i], nfr[i],
+                     motifs + motif_off[i], m, ref_size[i], max_iters[i], local_search_range[i], step_size[i]);
+    }
+    return ref_repeat_count_batch_impl(ctx, jobs, vcf_anchor_size, respect_coords, out9);
 }
 
 }  // extern "C"

@@ -9,11 +9,11 @@ call site whose behaviour it reproduces.  Pure Python/numpy host code: nothing h
 from .loci import Locus, LocusValidationError, load_loci, parse_last_column, parse_loci_bed, valid_motif, validate_locus
 from .fasta import Fasta, write_fasta
 from .bam import AlignedSegment, BamFile, read_bam, write_bam
-from .extract import (LocusReadCoords, LowMeanBaseQual, find_pair_by_ref_pos, get_aligned_pairs,
-                      get_read_coords_from_matched_pairs, get_sequence_data_for_locus)
+from .extract import (CigarIndex, LocusReadCoords, LowMeanBaseQual, find_pair_by_ref_pos, get_aligned_pairs,
+                      get_read_coords_from_cigar, get_read_coords_from_matched_pairs, get_sequence_data_for_locus)
 from .call import call_sample, write_json
 
 __all__ = ["Locus", "LocusValidationError", "load_loci", "parse_last_column", "parse_loci_bed", "valid_motif",
            "validate_locus", "Fasta", "write_fasta", "AlignedSegment", "BamFile", "read_bam", "write_bam",
-           "LocusReadCoords", "LowMeanBaseQual", "find_pair_by_ref_pos", "get_aligned_pairs",
+           "CigarIndex", "LocusReadCoords", "LowMeanBaseQual", "find_pair_by_ref_pos", "get_aligned_pairs", "get_read_coords_from_cigar",
            "get_read_coords_from_matched_pairs", "get_sequence_data_for_locus", "call_sample", "write_json"]

@@ -16,25 +16,25 @@ from .. import _lib
 from ..batch import count_loci, filter_reads
 from ..realign import realign_reads
 from ..repeat_count_params import get_reference_rc_params
-from ..repeats import get_ref_repeat_count
+from ..repeats import get_ref_repeat_counts
 from ..segment import calculate_seq_with_wildcards
 from ..synth import LocusBatch
 from .bam import BamFile, read_bam
-from .extract import (LowMeanBaseQual, MIN_AVG_PHRED, get_aligned_pairs, get_read_coords_from_matched_pairs,
+from .extract import (LowMeanBaseQual, MIN_AVG_PHRED, get_read_coords_from_cigar, get_read_coords_from_matched_pairs,
                       get_sequence_data_for_locus)
 from .fasta import Fasta
 from .loci import Locus, load_loci
 
-__all__ = ["call_sample", "write_json", "get_locus_with_ref_data", "MAX_READS"]
+__all__ = ["call_sample", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
 
 MAX_READS = 250                 # params.max_reads default (strkit/call/params.py:21)
 DEFAULT_REF_MAX_ITERS = 100     # call_locus.py: default_ref_max_iters
 VCF_ANCHOR_SIZE = 5             # params.vcf_anchor_size default
 
 
-def get_locus_with_ref_data(locus: Locus, ref: Fasta, respect_ref: bool = False) -> dict | None:
-    """call_locus.py:736-835: reference window, reference copy number by the same counter, boundaries widened by the
-    offsets it found.  Returns None where the reference raises SkipLocus / InvalidLocus."""
+def _ref_window(locus: Locus, ref: Fasta):
+    """Reference window of a locus split into flank / tract / flank, or None where the reference raises SkipLocus /
+    InvalidLocus (call_locus.py:765-787)."""
     try:
         total = ref.fetch(locus.contig, locus.left_flank_coord, locus.right_flank_coord + 1)
     except (IndexError, KeyError):
@@ -46,13 +46,35 @@ def get_locus_with_ref_data(locus: Locus, ref: Fasta, respect_ref: bool = False)
     n_run = "N" * locus.motif_size
     if fl.endswith(n_run) or fr.startswith(n_run):
         return None                                           # "reference has flanking N[...] sequence"
-    est = round(len(tr) / locus.motif_size)
-    (ref_cn, _), l_off, r_off, n_is, (fl2, tr2, fr2) = get_ref_repeat_count(
-        est, tr, fl, fr, locus.motif, ref_size=locus.right_coord - locus.left_coord, vcf_anchor_size=VCF_ANCHOR_SIZE,
-        rc_params=get_reference_rc_params("repalign", est, DEFAULT_REF_MAX_ITERS), respect_coords=respect_ref)
-    return {"ref_cn": ref_cn, "ref_total_seq": total, "ref_seq": tr2, "ref_left_flank_seq": fl2, "ref_right_flank_seq": fr2,
-            "left_coord_adj": locus.left_coord if respect_ref else locus.left_coord - max(0, l_off),
-            "right_coord_adj": locus.right_coord if respect_ref else locus.right_coord + max(0, r_off)}
+    return total, fl, tr, fr
+
+
+def get_loci_with_ref_data(block: list[Locus], ref: Fasta, respect_ref: bool = False, context=None) -> list[dict | None]:
+    """call_locus.py:736-835 for a block of loci: reference windows, reference copy numbers by the same counter (all
+    loci in one batched library call), boundaries widened by the offsets it found.  None per skipped locus."""
+    windows = [_ref_window(locus, ref) for locus in block]
+    jobs, idx = [], []
+    for i, (locus, w) in enumerate(zip(block, windows)):
+        if w is None:
+            continue
+        _, fl, tr, fr = w
+        est = round(len(tr) / locus.motif_size)
+        jobs.append((est, tr, fl, fr, locus.motif, locus.right_coord - locus.left_coord,
+                     get_reference_rc_params("repalign", est, DEFAULT_REF_MAX_ITERS)))
+        idx.append(i)
+    out: list[dict | None] = [None] * len(block)
+    for i, ((ref_cn, _), l_off, r_off, _n_is, (fl2, tr2, fr2)) in zip(
+            idx, get_ref_repeat_counts(jobs, VCF_ANCHOR_SIZE, respect_ref, context)):
+        locus = block[i]
+        out[i] = {"ref_cn": ref_cn, "ref_total_seq": windows[i][0], "ref_seq": tr2, "ref_left_flank_seq": fl2,
+                  "ref_right_flank_seq": fr2,
+                  "left_coord_adj": locus.left_coord if respect_ref else locus.left_coord - max(0, l_off),
+                  "right_coord_adj": locus.right_coord if respect_ref else locus.right_coord + max(0, r_off)}
+    return out
+
+
+def get_locus_with_ref_data(locus: Locus, ref: Fasta, respect_ref: bool = False, context=None) -> dict | None:
+    return get_loci_with_ref_data([locus], ref, respect_ref, context)[0]
 
 
 def _locus_dict(locus: Locus) -> dict:
@@ -71,11 +93,15 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
     t0 = time.perf_counter()
     results: list[dict] = []
     n_depth = 0
+    tm = {"ref_side_s": 0.0, "realign_s": 0.0, "extract_s": 0.0, "count_s": 0.0}
+
     for block in load_loci(loci_file, flank_size, contigs=set(bam.references) & set(ref.references)):
         prepared = []                     # (locus, ref data, [(segment, query_coords, ref_coords) ...])
         realign_jobs = []                 # (index into prepared, index of the segment)
-        for locus in block:
-            rd = get_locus_with_ref_data(locus, ref, respect_ref)
+        t_a = time.perf_counter()
+        ref_data = get_loci_with_ref_data(block, ref, respect_ref, ctx)
+        tm["ref_side_s"] += time.perf_counter() - t_a
+        for locus, rd in zip(block, ref_data):
             if rd is None:
                 results.append(_locus_dict(locus))    # SkipLocus: locus fields + empty call (call_locus.py:1032-1036)
                 continue
@@ -86,6 +112,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
                     realign_jobs.append((len(prepared), len(entries)))
                 entries.append([seg, None, False])
             prepared.append((locus, rd, entries))
+        t_a = time.perf_counter()
         if realign_jobs:                  # every soft-clipped read of the block in one device call (realign.py:75-154)
             refs_, reads_, lfcs = [], [], []
             for pi, ei in realign_jobs:
@@ -98,14 +125,19 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
                 if ac is not None:
                     prepared[pi][2][ei][1] = (ac.query_coords, ac.ref_coords)
                     prepared[pi][2][ei][2] = True
+        tm["realign_s"] += time.perf_counter() - t_a
+        t_a = time.perf_counter()
         # triples of every read of the block -> one batched device call
         loci_reads, meta = [], []
         for locus, rd, entries in prepared:
             triples, names = [], []
             for seg, pairs, realigned in entries:
-                qc, rc = pairs if pairs is not None else get_aligned_pairs(seg)
-                coords = get_read_coords_from_matched_pairs(locus.left_flank_coord, rd["left_coord_adj"],
-                                                            rd["right_coord_adj"], locus.right_flank_coord, qc, rc)
+                if pairs is not None:     # realigned: the pairs of the new alignment
+                    coords = get_read_coords_from_matched_pairs(locus.left_flank_coord, rd["left_coord_adj"],
+                                                                rd["right_coord_adj"], locus.right_flank_coord, *pairs)
+                else:
+                    coords = get_read_coords_from_cigar(locus.left_flank_coord, rd["left_coord_adj"],
+                                                        rd["right_coord_adj"], locus.right_flank_coord, seg)
                 if coords.is_incomplete():
                     continue
                 try:
@@ -119,8 +151,11 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
         if not prepared:
             continue
         batch = LocusBatch.from_reads(loci_reads)
+        tm["extract_s"] += time.perf_counter() - t_a
+        t_a = time.perf_counter()
         res = count_loci(batch, ctx=ctx) if batch.n_reads else {k: np.zeros(0, np.int32) for k in ("cn", "score", "n_iters", "start")}
         flt = filter_reads(batch, res) if batch.n_reads else {"sc": np.zeros(0), "keep": np.zeros(0, bool), "locus_ok": np.ones(batch.n_loci, bool)}
+        tm["count_s"] += time.perf_counter() - t_a
         for li, (locus, rd, _) in enumerate(prepared):
             r0, r1 = int(batch.read_off[li]), int(batch.read_off[li + 1])
             kept = [r for r in range(r0, r1) if flt["keep"][r]]
@@ -150,7 +185,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
             "catalog": {"num_loci": len(results)},
             "results": results,
             "avg_read_depth": n_depth / max(1, sum(1 for r in results if "reads" in r)),
-            "runtime": time.perf_counter() - t0}
+            "runtime": time.perf_counter() - t0, "stage_times": {k: round(v, 4) for k, v in tm.items()}}
 
 
 def write_json(report: dict, path: str) -> None:

@@ -21,8 +21,8 @@ import numpy as np
 
 from ..segment import BASE_WILDCARD_THRESHOLD, calculate_seq_with_wildcards
 
-__all__ = ["LocusReadCoords", "LowMeanBaseQual", "find_pair_by_ref_pos", "get_aligned_pairs",
-           "get_read_coords_from_matched_pairs", "get_sequence_data_for_locus", "SequenceDataForLocus",
+__all__ = ["LocusReadCoords", "LowMeanBaseQual", "find_pair_by_ref_pos", "get_aligned_pairs", "CigarIndex",
+           "get_read_coords_from_matched_pairs", "get_read_coords_from_cigar", "get_sequence_data_for_locus", "SequenceDataForLocus",
            "MIN_AVG_PHRED", "FLANK_LEEWAY"]
 
 MIN_AVG_PHRED = 13   # params.min_avg_phred default (strkit/call/params.py)
@@ -52,6 +52,43 @@ def get_aligned_pairs(segment) -> tuple[np.ndarray, np.ndarray]:
         return e, e.copy()
     within = np.arange(int(ln.sum()), dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
     return np.repeat(q0[al], ln) + within, np.repeat(r0[al], ln) + within
+
+
+class CigarIndex:
+    """The aligned (M, =, X) runs of one segment: pair lookups without expanding every aligned pair.
+
+    Pair index k counts aligned columns from the start of the read's alignment; `first_pair_at_or_after(c)` is
+    find_pair_by_ref_pos on the expanded pair list."""
+
+    __slots__ = ("q0", "r0", "ln", "k0", "n_pairs")
+
+    def __init__(self, segment):
+        ops = (segment.cigar & 15).astype(np.int64)
+        lens = (segment.cigar >> 4).astype(np.int64)
+        q0 = np.concatenate(([0], np.cumsum(lens * _CONSUMES_QUERY[ops])[:-1]))
+        r0 = segment.start + np.concatenate(([0], np.cumsum(lens * _CONSUMES_REF[ops])[:-1]))
+        al = _ALIGNED[ops]
+        self.q0, self.r0, self.ln = q0[al], r0[al], lens[al]
+        self.k0 = np.concatenate(([0], np.cumsum(self.ln)[:-1])) if self.ln.size else np.zeros(0, np.int64)
+        self.n_pairs = int(self.ln.sum())
+
+    def first_ref(self) -> int:
+        return int(self.r0[0])
+
+    def last_ref(self) -> int:
+        return int(self.r0[-1] + self.ln[-1] - 1)
+
+    def first_pair_at_or_after(self, c: int) -> int:
+        """Index of the first aligned pair whose reference coordinate is >= c (n_pairs if none)."""
+        i = int(np.searchsorted(self.r0 + self.ln, c, side="right"))   # first run that ends past c
+        if i >= self.ln.size:
+            return self.n_pairs
+        return int(self.k0[i] + max(0, c - int(self.r0[i])))
+
+    def query_at(self, k: int) -> int:
+        """Read position of aligned pair k."""
+        i = int(np.searchsorted(self.k0, k, side="right")) - 1
+        return int(self.q0[i] + (k - int(self.k0[i])))
 
 
 def find_pair_by_ref_pos(ref_coords, target: int) -> tuple[int, bool]:
@@ -115,6 +152,35 @@ class SequenceDataForLocus:
         return round(len(self.tr_seq_wc) / motif_size)      # same expression as call_locus.py:796 on the read tract
 
 
+def get_read_coords_from_cigar(left_flank_coord: int, left_coord: int, right_coord: int, right_flank_coord: int,
+                               segment, allow_only_one_full_flank: bool = False) -> LocusReadCoords:
+    """get_read_coords_from_matched_pairs on the segment's own alignment, computed from the CIGAR runs (same result,
+    tests/test_frontend.py checks them against each other)."""
+    out = LocusReadCoords()
+    ix = CigarIndex(segment)
+    n = ix.n_pairs
+    if n == 0:
+        return out
+    out.full_left_flank = ix.first_ref() <= left_flank_coord
+    out.full_right_flank = ix.last_ref() >= right_flank_coord - 1
+    if not (out.full_left_flank and out.full_right_flank):
+        if not allow_only_one_full_flank or not (out.full_left_flank or out.full_right_flank):
+            return out
+    i_lfs = ix.first_pair_at_or_after(left_flank_coord)
+    i_l = ix.first_pair_at_or_after(left_coord)
+    i_r = ix.first_pair_at_or_after(right_coord)
+    i_rfe = ix.first_pair_at_or_after(right_flank_coord)
+    if i_l == 0 or i_r >= n:
+        return out
+    out.left_flank_start = ix.query_at(min(i_lfs, n - 1))
+    out.left_flank_end = ix.query_at(i_l - 1) + 1
+    out.right_flank_start = ix.query_at(i_r)
+    out.right_flank_end = ix.query_at(i_rfe) if i_rfe < n else ix.query_at(n - 1) + 1
+    if out.left_flank_end > out.right_flank_start:
+        out.right_flank_start = out.left_flank_end
+    return out
+
+
 def get_sequence_data_for_locus(segment, coords: LocusReadCoords, flank_size: int, min_avg_phred: int = MIN_AVG_PHRED,
                                 base_wildcard_threshold: int = BASE_WILDCARD_THRESHOLD) -> SequenceDataForLocus:
     qs, quals = segment.query_sequence, segment.query_qualities
@@ -123,8 +189,8 @@ def get_sequence_data_for_locus(segment, coords: LocusReadCoords, flank_size: in
         mean_q = float(np.mean(quals[b:c]))
         if mean_q < min_avg_phred:
             raise LowMeanBaseQual(mean_q)
-    wc = calculate_seq_with_wildcards(qs, quals, base_wildcard_threshold)
     keep = flank_size + FLANK_LEEWAY
-    fl = wc[a:b][-keep:]
-    fr = wc[c:d][:keep]
-    return SequenceDataForLocus(fl, wc[b:c], fr, qs[b:c], len(fl) + (c - b) + len(fr))
+    a2, d2 = max(a, b - keep), min(d, c + keep)     # only the part that is kept needs wildcards
+    wc = calculate_seq_with_wildcards(qs[a2:d2], None if quals is None else quals[a2:d2], base_wildcard_threshold)
+    fl, tr, fr = wc[:b - a2], wc[b - a2:c - a2], wc[c - a2:]
+    return SequenceDataForLocus(fl, tr, fr, qs[b:c], len(fl) + (c - b) + len(fr))

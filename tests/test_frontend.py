@@ -133,3 +133,22 @@ def test_synthetic_dataset_extraction_recovers_the_alleles(tmp_path):
             assert sd.tr_seq == truth["motif"] * truth["reads"][s.name]
             assert sd.flank_left_seq_wc[-70:] == ref.fetch(locus.contig, locus.left_flank_coord, locus.left_coord)
             assert sd.flank_right_seq_wc[:70] == ref.fetch(locus.contig, locus.right_coord, locus.right_flank_coord)
+
+
+def test_cigar_run_lookup_equals_expanded_pairs(tmp_path):
+    from strkit_amd.frontend import get_read_coords_from_cigar
+    t = make_dataset(str(tmp_path), n_loci=8, reads_per_locus=8, read_len=1500, seed=21, sub=0.02, indel=0.03,
+                     soft_clip_frac=0.4, expansion=12)
+    bam = read_bam(t["paths"]["bam"])
+    (block,) = load_loci(t["paths"]["loci"])
+    n = 0
+    for locus in block:
+        for s in bam.fetch(locus.contig, locus.left_flank_coord, locus.right_flank_coord):
+            q, r = get_aligned_pairs(s)
+            for shift in (0, -3, 5):
+                args = (locus.left_flank_coord + shift, locus.left_coord + shift, locus.right_coord - shift, locus.right_flank_coord - shift)
+                a = get_read_coords_from_matched_pairs(*args, q, r)
+                b = get_read_coords_from_cigar(*args, s)
+                assert a == b, (s.name, shift)
+                n += not a.is_incomplete()
+    assert n > 100

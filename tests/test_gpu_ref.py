@@ -76,3 +76,39 @@ def test_ref_schedule_with_big_steps(gpu_ctx):
                                       rc.initial_step_size)
         got = get_ref_repeat_count(est, tr, fl, fr, motif, len(tr), 5, rc)
         assert got == exp
+
+
+def test_batched_reference_side_equals_scalar_and_oracle(gpu_ctx):
+    """strk_ref_repeat_count_batch (lock-step rounds over a block of loci) == one strk_ref_repeat_count per locus ==
+    the oracle, including loci whose schedule differs (large estimates search in bigger steps)."""
+    import numpy as np
+    from helpers import rand_seq
+    from strkit_amd.repeat_count_params import get_reference_rc_params
+    from strkit_amd.repeats import get_ref_repeat_count, get_ref_repeat_counts
+    rng = np.random.default_rng(77)
+    jobs = []
+    for k in range(40):
+        m = int(rng.integers(1, 8))
+        motif = rand_seq(rng, m)
+        cn = int(rng.integers(2, 400 if k % 7 == 0 else 60))
+        fl, fr = rand_seq(rng, 70), rand_seq(rng, 70)
+        # the tract spills a little into the flanks so that the boundary extension has something to find
+        tr = motif * cn
+        if k % 3 == 0:
+            fl = fl[:70 - m] + motif
+        if k % 4 == 0:
+            fr = motif + fr[m:]
+        if k % 5 == 0:
+            tr = tr[:len(tr) // 2] + rand_seq(rng, 2) + tr[len(tr) // 2:]
+        est = max(0, round(len(tr) / m) + int(rng.integers(-2, 3)))
+        jobs.append((est, tr, fl, fr, motif, len(tr), get_reference_rc_params("repalign", est, 100)))
+    assert len({(j[6].max_iters, j[6].initial_local_search_range, j[6].initial_step_size) for j in jobs}) > 1
+    for respect in (False, True):
+        batch = get_ref_repeat_counts(jobs, 5, respect)
+        for job, got in zip(jobs, batch):
+            est, tr, fl, fr, motif, ref_size, rc = job
+            assert got == get_ref_repeat_count(est, tr, fl, fr, motif, ref_size, 5, rc, respect)
+            exp = oracle.ref_repeat_count(est, tr, fl, fr, motif, ref_size, 5, rc.max_iters, rc.initial_local_search_range,
+                                          rc.initial_step_size, respect)
+            assert got == exp
+    assert get_ref_repeat_counts([], 5) == []
