@@ -19,10 +19,22 @@ def main(argv=None) -> int:
     c.add_argument("--max-reads", type=int, default=250)
     c.add_argument("--realign", action="store_true")
     c.add_argument("--respect-ref", action="store_true")
+    # same names as `strkit call` (strkit/entry.py:20-342); --seed is accepted for command-line compatibility (the
+    # per-read path has no random component), --processes sizes the locus blocks as the reference does (loci.py:193)
+    c.add_argument("--sample-id", default=None)
+    c.add_argument("--processes", type=int, default=1)
+    c.add_argument("--seed", type=int, default=None)
+    c.add_argument("--rc-method", choices=("repalign",), default="repalign")
+    c.add_argument("--max-rcn-iters", type=int, default=50)
+    c.add_argument("--min-read-align-score", type=float, default=0.1)
     a = ap.parse_args(argv)
     from .frontend import call_sample, write_json
+    from .repeat_count_params import RepeatCountParams
+    rc = RepeatCountParams("repalign", a.max_rcn_iters, 3, 1)   # params.py:26-27,45
     rep = call_sample(a.read_file, a.ref, a.loci, flank_size=a.flank_size, realign=a.realign,
-                      min_avg_phred=a.min_avg_phred, max_reads=a.max_reads, respect_ref=a.respect_ref)
+                      min_avg_phred=a.min_avg_phred, max_reads=a.max_reads, respect_ref=a.respect_ref,
+                      sample_id=a.sample_id, processes=a.processes, rc_params=rc,
+                      min_read_align_score=a.min_read_align_score)
     if a.json == "-":
         import json
         json.dump(rep, sys.stdout, indent=1)

@@ -13,9 +13,9 @@ import time
 import numpy as np
 
 from .. import _lib
-from ..batch import count_loci, filter_reads
+from ..batch import MIN_READ_ALIGN_SCORE, count_loci, filter_reads
 from ..realign import realign_reads
-from ..repeat_count_params import get_reference_rc_params
+from ..repeat_count_params import RepeatCountParams, get_reference_rc_params
 from ..repeats import get_ref_repeat_counts
 from ..segment import calculate_seq_with_wildcards
 from ..synth import LocusBatch
@@ -25,7 +25,7 @@ from .extract import (LowMeanBaseQual, MIN_AVG_PHRED, get_read_coords_from_cigar
 from .fasta import Fasta
 from .loci import Locus, load_loci
 
-__all__ = ["call_sample", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
+__all__ = ["call_sample", "call_locus", "call_blocks", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
 
 MAX_READS = 250                 # params.max_reads default (strkit/call/params.py:21)
 DEFAULT_REF_MAX_ITERS = 100     # call_locus.py: default_ref_max_iters
@@ -84,18 +84,49 @@ def _locus_dict(locus: Locus) -> dict:
             "call_95_cis": None, "call_99_cis": None}
 
 
+def call_locus(locus: Locus, bam: BamFile, ref: Fasta, flank_size: int = 70, realign: bool = False,
+               min_avg_phred: int = MIN_AVG_PHRED, max_reads: int = MAX_READS, respect_ref: bool = False,
+               rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE,
+               ctx: _lib.Context | None = None) -> dict:
+    """The per-locus entry point (strkit/call/call_locus.py:974-995) over this backend: one locus, its LocusResult
+    record up to the read records (a block of one through the same path as call_sample)."""
+    return call_blocks([[locus]], bam, ref, flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params,
+                       min_read_align_score, ctx)[0][0]
+
+
 def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size: int = 70, realign: bool = False,
                 min_avg_phred: int = MIN_AVG_PHRED, max_reads: int = MAX_READS, respect_ref: bool = False,
-                sample_id: str | None = None, ctx: _lib.Context | None = None) -> dict:
+                sample_id: str | None = None, ctx: _lib.Context | None = None, processes: int = 1,
+                rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE) -> dict:
     bam = read_bam(bam) if isinstance(bam, str) else bam
     ref = Fasta(ref) if isinstance(ref, str) else ref
-    ctx = ctx or _lib.default_context()
     t0 = time.perf_counter()
+    blocks = load_loci(loci_file, flank_size, contigs=set(bam.references) & set(ref.references), processes=processes)
+    results, n_depth, tm = call_blocks(blocks, bam, ref, flank_size, realign, min_avg_phred, max_reads, respect_ref,
+                                       rc_params, min_read_align_score, ctx)
+    # same top-level layout as the reference's report (strkit/call/output/json_report.py:37-60,127-154)
+    return {"sample_id": sample_id,
+            "caller": {"name": "strkit_amd", "version": _lib.load().strk_version().decode()},
+            "parameters": {"flank_size": flank_size, "realign": realign, "min_avg_phred": min_avg_phred,
+                           "max_reads": max_reads, "respect_ref": respect_ref, "rc_method": "repalign",
+                           "min_read_align_score": min_read_align_score, "processes": processes},
+            "contigs": sorted({r["contig"] for r in results}),
+            "catalog": {"num_loci": len(results)},
+            "results": results,
+            "avg_read_depth": n_depth / max(1, sum(1 for r in results if "reads" in r)),
+            "runtime": time.perf_counter() - t0, "stage_times": {k: round(v, 4) for k, v in tm.items()}}
+
+
+def call_blocks(blocks, bam: BamFile, ref: Fasta, flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params,
+                min_read_align_score, ctx):
+    """Worker loop over blocks of loci (strkit/call/call_sample.py:103-197): (results in locus order, reads kept,
+    stage times)."""
+    ctx = ctx or _lib.default_context()
     results: list[dict] = []
     n_depth = 0
     tm = {"ref_side_s": 0.0, "realign_s": 0.0, "extract_s": 0.0, "count_s": 0.0}
 
-    for block in load_loci(loci_file, flank_size, contigs=set(bam.references) & set(ref.references)):
+    for block in blocks:
         prepared = []                     # (locus, ref data, [(segment, query_coords, ref_coords) ...])
         realign_jobs = []                 # (index into prepared, index of the segment)
         t_a = time.perf_counter()
@@ -153,8 +184,8 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
         batch = LocusBatch.from_reads(loci_reads)
         tm["extract_s"] += time.perf_counter() - t_a
         t_a = time.perf_counter()
-        res = count_loci(batch, ctx=ctx) if batch.n_reads else {k: np.zeros(0, np.int32) for k in ("cn", "score", "n_iters", "start")}
-        flt = filter_reads(batch, res) if batch.n_reads else {"sc": np.zeros(0), "keep": np.zeros(0, bool), "locus_ok": np.ones(batch.n_loci, bool)}
+        res = count_loci(batch, rc_params, ctx=ctx) if batch.n_reads else {k: np.zeros(0, np.int32) for k in ("cn", "score", "n_iters", "start")}
+        flt = filter_reads(batch, res, min_read_align_score) if batch.n_reads else {"sc": np.zeros(0), "keep": np.zeros(0, bool), "locus_ok": np.ones(batch.n_loci, bool)}
         tm["count_s"] += time.perf_counter() - t_a
         for li, (locus, rd, _) in enumerate(prepared):
             r0, r1 = int(batch.read_off[li]), int(batch.read_off[li + 1])
@@ -176,16 +207,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
             n_depth += len(row["reads"])
             results.append(row)
     results.sort(key=lambda r: r["locus_index"])
-    # same top-level layout as the reference's report (strkit/call/output/json_report.py:37-60,127-154)
-    return {"sample_id": sample_id,
-            "caller": {"name": "strkit_amd", "version": _lib.load().strk_version().decode()},
-            "parameters": {"flank_size": flank_size, "realign": realign, "min_avg_phred": min_avg_phred,
-                           "max_reads": max_reads, "respect_ref": respect_ref, "rc_method": "repalign"},
-            "contigs": sorted({r["contig"] for r in results}),
-            "catalog": {"num_loci": len(results)},
-            "results": results,
-            "avg_read_depth": n_depth / max(1, sum(1 for r in results if "reads" in r)),
-            "runtime": time.perf_counter() - t0, "stage_times": {k: round(v, 4) for k, v in tm.items()}}
+    return results, n_depth, tm
 
 
 def write_json(report: dict, path: str) -> None:

@@ -75,3 +75,12 @@ def test_cli_writes_json(gpu_ctx, tmp_path):
     assert main(["call", t["paths"]["bam"], "--ref", t["paths"]["ref"], "--loci", t["paths"]["loci"], "--json", out]) == 0
     rep = json.load(open(out))
     assert [r["ref_cn"] for r in rep["results"]] == [x["ref_cn"] for x in t["loci"]]
+    # the per-locus entry point gives the same record as the block path
+    from strkit_amd.frontend import Fasta, call_locus, load_loci, read_bam
+    bam, ref = read_bam(t["paths"]["bam"]), Fasta(t["paths"]["ref"])
+    (block,) = load_loci(t["paths"]["loci"])
+    one = call_locus(block[2], bam, ref)
+    assert json.loads(json.dumps(one)) == rep["results"][2]
+    assert main(["call", t["paths"]["bam"], "--ref", t["paths"]["ref"], "--loci", t["paths"]["loci"], "--json", out,
+                 "--processes", "2", "--max-rcn-iters", "30", "--min-read-align-score", "0.2", "--sample-id", "s1", "--seed", "7"]) == 0
+    assert json.load(open(out))["sample_id"] == "s1"
