@@ -201,6 +201,30 @@ int strk_realign(strk_ctx* ctx, int32_t n_pairs, const uint8_t* s1, const int64_
                  int32_t* out_end_ref, int32_t* out_n_cigar, uint32_t* cigar, const int64_t* cigar_off,
                  strk_stats* stats);
 
+/* ---- host-side front end (CPU only; no context, thread-safe) ---------------------------------------------------
+ * What the reference's Rust extension does before the counter runs: walk the alignment records
+ * (STRkitBAMReader / STRkitAlignedSegment, call sites strkit/call/call_sample.py:81-131) and cut each read into
+ * (left flank, tract, right flank) for a locus (get_read_coords_from_matched_pairs + get_sequence_data_for_locus,
+ * strkit/call/call_locus.py:875-877,1101-1146).  The rules are spelled out in strkit_amd/frontend/extract.py.
+ *
+ * strk_bam_scan: `buf` = the decompressed BAM stream, `first_rec` = byte offset of the first alignment record (after
+ * header and reference list).  Writes, for up to `cap` records, the record's byte offset, refID, 0-based start, exclusive
+ * reference end, flag, l_seq and the soft-clip lengths at its two ends; returns the number of records in the stream
+ * (call again with larger arrays if it exceeds `cap`) or a negative STRK_E_* code. */
+int64_t strk_bam_scan(const uint8_t* buf, int64_t n_bytes, int64_t first_rec, int64_t cap, int64_t* rec_off, int32_t* tid,
+                      int32_t* pos, int32_t* end, int32_t* flag, int32_t* l_seq, int32_t* clip_l, int32_t* clip_r);
+
+/* strk_extract_reads: item i = (record at rec_off[i], locus boundaries coords[4i..4i+3] = left_flank_coord, left_coord,
+ * right_coord, right_flank_coord).  An item with alt_cigar_off[i+1] > alt_cigar_off[i] uses that CIGAR (BAM encoding)
+ * starting at alt_start[i] instead of the record's own alignment (a realigned read); alt_* may be NULL.
+ * status[i]: 0 = extracted, 1 = the read does not span both flanks (skipped), 2 = mean base quality of the tract below
+ * min_avg_phred (skipped).  Extracted items append fl|tr|fr (flanks cut to flank_size, bases with PHRED <=
+ * wildcard_threshold replaced by 'X') to seqs; seq_off is [n_items + 1]; nfl/ntr/nfr the three lengths. */
+int strk_extract_reads(const uint8_t* buf, int64_t n_bytes, int32_t n_items, const int64_t* rec_off, const int64_t* coords,
+                       const uint32_t* alt_cigar, const int64_t* alt_cigar_off, const int64_t* alt_start, int32_t flank_size,
+                       int32_t min_avg_phred, int32_t wildcard_threshold, int32_t* status, int32_t* nfl, int32_t* ntr,
+                       int32_t* nfr, uint8_t* seqs, int64_t seq_cap, int64_t* seq_off);
+
 #ifdef __cplusplus
 }
 #endif

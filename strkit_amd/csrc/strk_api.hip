@@ -22,6 +22,7 @@
 #include "../../include/strkit_amd.h"
 #include "strk_kernels.h"
 #include "strk_realign.h"
+#include "strk_frontend.h"
 
 extern "C" int strk_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int32_t tr_len, const uint8_t* fl,
                                  int32_t fl_len, const uint8_t* fr, int32_t fr_len, const uint8_t* motif, int32_t motif_len,
@@ -1368,6 +1369,79 @@ int strk_ref_repeat_count_batch(strk_ctx* ctx, int32_t n_loci, const int32_t* st
                      motifs + motif_off[i], m, ref_size[i], max_iters[i], local_search_range[i], step_size[i]);
     }
     return ref_repeat_count_batch_impl(ctx, jobs, vcf_anchor_size, respect_coords, out9);
+}
+
+// ---- host-side front end (no device work, no context) -------------------------------------------------------------
+int64_t strk_bam_scan(const uint8_t* buf, int64_t n_bytes, int64_t first_rec, int64_t cap, int64_t* rec_off, int32_t* tid,
+                      int32_t* pos, int32_t* end, int32_t* flag, int32_t* l_seq, int32_t* clip_l, int32_t* clip_r) {
+    if (!buf || n_bytes < 0 || first_rec < 0 || cap < 0) return fail(STRK_E_INVALID, "bad argument");
+    if (cap > 0 && (!rec_off || !tid || !pos || !end || !flag || !l_seq || !clip_l || !clip_r)) return fail(STRK_E_INVALID, "NULL output array");
+    int64_t off = first_rec, n = 0;
+    while (off + 4 <= n_bytes) {
+        strk_fe::Rec r;
+        int64_t next = 0;
+        if (!strk_fe::parse_rec(buf, n_bytes, off, &r, &next)) return fail(STRK_E_INVALID, "malformed BAM record at byte %lld", (long long)off);
+        if (n < cap) {
+            int64_t ref_len = 0;
+            int32_t cl = 0, cr = 0;
+            for (int32_t i = 0; i < r.n_cigar; ++i) {
+                const uint32_t c = strk_fe::rd_u32(r.cigar + 4 * (size_t)i), op = c & 15u;
+                if (strk_fe::consumes_ref(op)) ref_len += c >> 4;
+                if (op == 4 && i == 0) cl = (int32_t)(c >> 4);
+                if (op == 4 && i == r.n_cigar - 1) cr = (int32_t)(c >> 4);
+            }
+            rec_off[n] = off; tid[n] = r.tid; pos[n] = r.pos; end[n] = (int32_t)(r.pos + ref_len); flag[n] = r.flag;
+            l_seq[n] = r.l_seq; clip_l[n] = cl; clip_r[n] = cr;
+        }
+        ++n;
+        off = next;
+    }
+    return n;
+}
+
+int strk_extract_reads(const uint8_t* buf, int64_t n_bytes, int32_t n_items, const int64_t* rec_off, const int64_t* coords,
+                       const uint32_t* alt_cigar, const int64_t* alt_cigar_off, const int64_t* alt_start, int32_t flank_size,
+                       int32_t min_avg_phred, int32_t wildcard_threshold, int32_t* status, int32_t* nfl, int32_t* ntr,
+                       int32_t* nfr, uint8_t* seqs, int64_t seq_cap, int64_t* seq_off) {
+    if (n_items < 0 || flank_size < 0) return fail(STRK_E_INVALID, "bad argument");
+    if (n_items == 0) { if (seq_off) seq_off[0] = 0; return 0; }
+    if (!buf || !rec_off || !coords || !status || !nfl || !ntr || !nfr || !seqs || !seq_off) return fail(STRK_E_INVALID, "NULL argument");
+    static const char kBases[] = "=ACMGRSVTWYHKDBN";
+    strk_fe::Runs runs;
+    int64_t w = 0;
+    seq_off[0] = 0;
+    for (int32_t it = 0; it < n_items; ++it) {
+        status[it] = 1; nfl[it] = ntr[it] = nfr[it] = 0;
+        seq_off[it + 1] = w;
+        strk_fe::Rec r;
+        int64_t next = 0;
+        if (!strk_fe::parse_rec(buf, n_bytes, rec_off[it], &r, &next)) return fail(STRK_E_INVALID, "item %d: malformed BAM record", it);
+        const bool alt = alt_cigar && alt_cigar_off && alt_cigar_off[it + 1] > alt_cigar_off[it];
+        if (alt) runs.build(reinterpret_cast<const uint8_t*>(alt_cigar + alt_cigar_off[it]), (int32_t)(alt_cigar_off[it + 1] - alt_cigar_off[it]), alt_start ? alt_start[it] : 0);
+        else runs.build(r.cigar, r.n_cigar, r.pos);
+        int64_t q[4];
+        if (!strk_fe::read_coords(runs, coords[4 * (size_t)it], coords[4 * (size_t)it + 1], coords[4 * (size_t)it + 2], coords[4 * (size_t)it + 3], q)) continue;
+        const int64_t b = q[1], c = q[2];
+        const int64_t a = std::max(q[0], b - flank_size), d = std::min(q[3], c + flank_size);
+        if (a < 0 || d > r.l_seq || a > b || b > c || c > d) continue;   // coordinates outside the read: incomplete
+        const bool has_qual = !(r.l_seq > 0 && r.qual[0] == 0xFF);
+        if (has_qual && c > b) {   // LowMeanBaseQual on the tract bases (call_locus.py:1099-1115)
+            int64_t sum = 0;
+            for (int64_t i = b; i < c; ++i) sum += r.qual[i];
+            if ((double)sum / (double)(c - b) < (double)min_avg_phred) { status[it] = 2; continue; }
+        }
+        if (w + (d - a) > seq_cap) return fail(STRK_E_NOMEM, "sequence buffer too small");
+        for (int64_t i = a; i < d; ++i) {
+            const uint8_t byte = r.seq[i >> 1];
+            char ch = kBases[(i & 1) ? (byte & 15) : (byte >> 4)];
+            if (has_qual && (int32_t)r.qual[i] <= wildcard_threshold) ch = 'X';   // call_locus.py:79,1101-1106
+            seqs[w++] = (uint8_t)ch;
+        }
+        status[it] = 0;
+        nfl[it] = (int32_t)(b - a); ntr[it] = (int32_t)(c - b); nfr[it] = (int32_t)(d - c);
+        seq_off[it + 1] = w;
+    }
+    return 0;
 }
 
 }  // extern "C"

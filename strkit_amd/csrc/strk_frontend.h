@@ -1,0 +1,111 @@
+// strk_frontend.h — host-side (CPU) front end: BAM record scan and read -> (left flank, tract, right flank)
+// extraction for blocks of (read, locus) pairs.  No device code.
+//
+// The reference does this in strkit_rust_ext (STRkitBAMReader, STRkitAlignedSegment.get_sequence_data_for_locus,
+// get_read_coords_from_matched_pairs; call sites strkit/call/call_locus.py:837-958,1082-1146); the readable
+// statement of the same rules is strkit_amd/frontend/extract.py, and tests/test_frontend.py checks this file
+// against it record by record.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+namespace strk_fe {
+
+inline int32_t rd_i32(const uint8_t* p) { int32_t v; memcpy(&v, p, 4); return v; }
+inline uint32_t rd_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint16_t rd_u16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+constexpr bool consumes_query(uint32_t op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
+constexpr bool consumes_ref(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+constexpr bool is_aligned(uint32_t op) { return op == 0 || op == 7 || op == 8; }
+
+// Fixed part of a BAM alignment record (after block_size): refID, pos, l_read_name, mapq, bin, n_cigar_op, flag,
+// l_seq, next_refID, next_pos, tlen = 32 bytes, then read_name, cigar, seq (4 bit), qual.
+struct Rec {
+    int32_t tid, pos, l_name, n_cigar, flag, l_seq;
+    const uint8_t* name;
+    const uint8_t* cigar;
+    const uint8_t* seq;
+    const uint8_t* qual;
+};
+inline bool parse_rec(const uint8_t* buf, int64_t n_bytes, int64_t off, Rec* r, int64_t* next) {
+    if (off + 4 > n_bytes) return false;
+    const int32_t block = rd_i32(buf + off);
+    if (block < 32 || off + 4 + block > n_bytes) return false;
+    const uint8_t* p = buf + off + 4;
+    r->tid = rd_i32(p);
+    r->pos = rd_i32(p + 4);
+    r->l_name = p[8];
+    r->n_cigar = rd_u16(p + 12);
+    r->flag = rd_u16(p + 14);
+    r->l_seq = rd_i32(p + 16);
+    const int64_t need = 32 + (int64_t)r->l_name + 4 * (int64_t)r->n_cigar + (r->l_seq + 1) / 2 + r->l_seq;
+    if (r->l_seq < 0 || need > block) return false;
+    r->name = p + 32;
+    r->cigar = r->name + r->l_name;
+    r->seq = r->cigar + 4 * (size_t)r->n_cigar;
+    r->qual = r->seq + (r->l_seq + 1) / 2;
+    *next = off + 4 + block;
+    return true;
+}
+
+// Aligned (M, =, X) runs of one alignment: read position, reference position, length, index of the first pair.
+struct Runs {
+    std::vector<int64_t> q0, r0, ln, k0;
+    int64_t n_pairs = 0;
+    void build(const uint8_t* cigar, int32_t n_cigar, int64_t start) {
+        q0.clear(); r0.clear(); ln.clear(); k0.clear();
+        n_pairs = 0;
+        int64_t q = 0, r = start;
+        for (int32_t i = 0; i < n_cigar; ++i) {
+            const uint32_t c = rd_u32(cigar + 4 * (size_t)i), op = c & 15u;
+            const int64_t len = c >> 4;
+            if (is_aligned(op) && len > 0) {
+                q0.push_back(q); r0.push_back(r); ln.push_back(len); k0.push_back(n_pairs);
+                n_pairs += len;
+            }
+            if (consumes_query(op)) q += len;
+            if (consumes_ref(op)) r += len;
+        }
+    }
+    // index of the first aligned pair whose reference coordinate is >= c (n_pairs if none)
+    int64_t first_pair_at_or_after(int64_t c) const {
+        size_t lo = 0, hi = ln.size();
+        while (lo < hi) {   // first run that ends past c
+            const size_t mid = (lo + hi) / 2;
+            if (r0[mid] + ln[mid] > c) hi = mid; else lo = mid + 1;
+        }
+        if (lo >= ln.size()) return n_pairs;
+        return k0[lo] + (c > r0[lo] ? c - r0[lo] : 0);
+    }
+    int64_t query_at(int64_t k) const {
+        size_t lo = 0, hi = k0.size();
+        while (lo < hi) {   // last run with k0 <= k
+            const size_t mid = (lo + hi) / 2;
+            if (k0[mid] <= k) lo = mid + 1; else hi = mid;
+        }
+        const size_t i = lo - 1;
+        return q0[i] + (k - k0[i]);
+    }
+};
+
+// Read positions of the four locus boundaries (extract.py: get_read_coords_from_cigar).  false = incomplete.
+inline bool read_coords(const Runs& ix, int64_t lfc, int64_t lc, int64_t rc, int64_t rfc, int64_t out[4]) {
+    const int64_t n = ix.n_pairs;
+    if (n == 0) return false;
+    const bool full_l = ix.r0.front() <= lfc, full_r = ix.r0.back() + ix.ln.back() - 1 >= rfc - 1;
+    if (!(full_l && full_r)) return false;
+    const int64_t i_lfs = ix.first_pair_at_or_after(lfc), i_l = ix.first_pair_at_or_after(lc);
+    const int64_t i_r = ix.first_pair_at_or_after(rc), i_rfe = ix.first_pair_at_or_after(rfc);
+    if (i_l == 0 || i_r >= n) return false;
+    out[0] = ix.query_at(i_lfs < n - 1 ? i_lfs : n - 1);
+    out[1] = ix.query_at(i_l - 1) + 1;     // bases inserted at a tract boundary belong to the tract
+    out[2] = ix.query_at(i_r);
+    out[3] = i_rfe < n ? ix.query_at(i_rfe) : ix.query_at(n - 1) + 1;
+    if (out[1] > out[2]) out[2] = out[1];
+    return true;
+}
+
+}  // namespace strk_fe

@@ -151,7 +151,7 @@ def _bgzf_blocks(data: bytes) -> bytes:
     out = bytearray()
     for i in range(0, len(data), 0xFF00):
         chunk = data[i:i + 0xFF00]
-        comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = zlib.compressobj(1, zlib.DEFLATED, -15)
         body = comp.compress(chunk) + comp.flush()
         bsize = len(body) + 25
         out += struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, bsize)
@@ -167,11 +167,16 @@ def write_bam(path: str, contigs: list[tuple[str, int]], records: list[dict]) ->
     buf = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(contigs)))
     for n, ln in contigs:
         buf += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", ln)
-    code = {c: i for i, c in enumerate(_SEQ_CODES)}
+    lut = np.full(256, 15, np.uint8)
+    for i, ch in enumerate(_SEQ_CODES):
+        lut[ord(ch)] = i
+        lut[ord(ch.lower())] = i
     for r in records:
         cig = np.array([(ln << 4) | CIGAR_OPS.index(op) for ln, op in r["cigar"]], np.uint32)
         seq = r["seq"]
-        nib = np.array([code.get(ch, 15) for ch in seq.upper()] + ([0] if len(seq) & 1 else []), np.uint8)
+        nib = lut[np.frombuffer(seq.encode("ascii"), np.uint8)]
+        if len(seq) & 1:
+            nib = np.concatenate((nib, np.zeros(1, np.uint8)))
         packed = ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8)
         qual = r.get("qual")
         qb = bytes([0xFF]) * len(seq) if qual is None else np.asarray(qual, np.uint8).tobytes()

@@ -14,7 +14,7 @@ import numpy as np
 
 from .. import _lib
 from ..batch import MIN_READ_ALIGN_SCORE, count_loci, filter_reads
-from ..realign import realign_reads
+from ..realign import _gate as realign_gate, realign_pairs, realign_reads
 from ..repeat_count_params import RepeatCountParams, get_reference_rc_params
 from ..repeats import get_ref_repeat_counts
 from ..segment import calculate_seq_with_wildcards
@@ -24,6 +24,7 @@ from .extract import (LowMeanBaseQual, MIN_AVG_PHRED, get_read_coords_from_cigar
                       get_sequence_data_for_locus)
 from .fasta import Fasta
 from .loci import Locus, load_loci
+from .native import NativeBam, extract_reads, realign_cigar_to_read_alignment
 
 __all__ = ["call_sample", "call_locus", "call_blocks", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
 
@@ -98,7 +99,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
                 min_avg_phred: int = MIN_AVG_PHRED, max_reads: int = MAX_READS, respect_ref: bool = False,
                 sample_id: str | None = None, ctx: _lib.Context | None = None, processes: int = 1,
                 rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE) -> dict:
-    bam = read_bam(bam) if isinstance(bam, str) else bam
+    bam = NativeBam(bam) if isinstance(bam, str) else bam      # a path: records stay in the decompressed stream
     ref = Fasta(ref) if isinstance(ref, str) else ref
     t0 = time.perf_counter()
     blocks = load_loci(loci_file, flank_size, contigs=set(bam.references) & set(ref.references), processes=processes)
@@ -122,6 +123,9 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, flank_size, realign, min_avg_p
     """Worker loop over blocks of loci (strkit/call/call_sample.py:103-197): (results in locus order, reads kept,
     stage times)."""
     ctx = ctx or _lib.default_context()
+    if isinstance(bam, NativeBam):
+        return _call_blocks_native(blocks, bam, ref, flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params,
+                                   min_read_align_score, ctx)
     results: list[dict] = []
     n_depth = 0
     tm = {"ref_side_s": 0.0, "realign_s": 0.0, "extract_s": 0.0, "count_s": 0.0}
@@ -206,6 +210,105 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, flank_size, realign, min_avg_p
             row["reads"] = reads if flt["locus_ok"][li] else {}
             n_depth += len(row["reads"])
             results.append(row)
+    results.sort(key=lambda r: r["locus_index"])
+    return results, n_depth, tm
+
+
+def _call_blocks_native(blocks, bam, ref: Fasta, flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params,
+                        min_read_align_score, ctx):
+    """call_blocks over a NativeBam: per block ONE strk_extract_reads call cuts every read of every locus; Python only
+    loops over loci (fetch by numpy) and over the reads that end up in the report."""
+    results: list[dict] = []
+    n_depth = 0
+    tm = {"ref_side_s": 0.0, "realign_s": 0.0, "extract_s": 0.0, "count_s": 0.0}
+    for block in blocks:
+        t_a = time.perf_counter()
+        ref_data = get_loci_with_ref_data(block, ref, respect_ref, ctx)
+        tm["ref_side_s"] += time.perf_counter() - t_a
+        t_a = time.perf_counter()
+        live, rec_parts, coord_parts, counts = [], [], [], []
+        for locus, rd in zip(block, ref_data):
+            if rd is None:
+                results.append(_locus_dict(locus))
+                continue
+            idx = bam.fetch_indices(locus.contig, locus.left_flank_coord, locus.right_flank_coord)[:max_reads]
+            live.append((locus, rd))
+            rec_parts.append(idx)
+            coord_parts.append(np.tile(np.array([locus.left_flank_coord, rd["left_coord_adj"], rd["right_coord_adj"],
+                                                 locus.right_flank_coord], np.int64), (len(idx), 1)))
+            counts.append(len(idx))
+        if not live:
+            continue
+        rec = np.concatenate(rec_parts) if rec_parts else np.zeros(0, np.int64)
+        coords = np.concatenate(coord_parts) if coord_parts else np.zeros((0, 4), np.int64)
+        item_locus = np.repeat(np.arange(len(live)), counts)
+        tm["extract_s"] += time.perf_counter() - t_a
+        alt = None
+        if realign and rec.size:          # soft-clipped reads of the whole block in one device call (realign.py:75-154)
+            t_a = time.perf_counter()
+            lf = np.array([l.left_flank_coord for l, _ in live], np.int64)[item_locus]
+            rf = np.array([l.right_flank_coord for l, _ in live], np.int64)[item_locus]
+            left = (bam.clip_l[rec] > 0) & (bam.pos[rec] >= lf) & (bam.pos[rec] <= rf)
+            right = (bam.clip_r[rec] > 0) & (bam.end[rec] >= lf) & (bam.end[rec] <= rf)
+            cand = np.nonzero(left | right)[0]
+            if cand.size:
+                refs_, reads_ = [], []
+                for it in cand:
+                    seg = bam.segment(int(rec[it]))
+                    refs_.append(live[int(item_locus[it])][1]["ref_total_seq"])
+                    reads_.append(calculate_seq_with_wildcards(seg.query_sequence, seg.query_qualities, 3))
+                gate = realign_gate(flank_size)
+                alt = {}
+                for it, (sc, _e, cg) in zip(cand, realign_pairs(refs_, reads_, context=ctx)):
+                    if sc >= gate:
+                        alt[int(it)] = (realign_cigar_to_read_alignment(cg), int(lf[it]))
+            tm["realign_s"] += time.perf_counter() - t_a
+        t_a = time.perf_counter()
+        ex = extract_reads(bam, rec, coords, flank_size, min_avg_phred, 3, alt)
+        ok = ex["status"] == 0
+        n_ok_per_locus = np.bincount(item_locus[ok], minlength=len(live))
+        motifs = [l.motif.encode() for l, _ in live]
+        m_per_item = np.array([len(m) for m in motifs], np.int64)[item_locus[ok]]
+        ntr_ok = ex["ntr"][ok]
+        batch = LocusBatch(
+            seqs=ex["seqs"], seq_off=np.concatenate(([0], ex["seq_off"][1:][ok])).astype(np.int64),
+            nfl=ex["nfl"][ok], ntr=ntr_ok, nfr=ex["nfr"][ok],
+            est_cn=np.rint(ntr_ok / m_per_item).astype(np.int32),          # round(len(tr) / motif_size), half to even
+            read_off=np.concatenate(([0], np.cumsum(n_ok_per_locus))).astype(np.int32),
+            motifs=np.frombuffer(b"".join(motifs), np.uint8).copy(),
+            motif_off=np.concatenate(([0], np.cumsum([len(m) for m in motifs]))).astype(np.int32))
+        tm["extract_s"] += time.perf_counter() - t_a
+        t_a = time.perf_counter()
+        if batch.n_reads:
+            res = count_loci(batch, rc_params, ctx=ctx)
+            flt = filter_reads(batch, res, min_read_align_score)
+        else:
+            res = {k: np.zeros(0, np.int32) for k in ("cn", "score", "n_iters", "start")}
+            flt = {"sc": np.zeros(0), "keep": np.zeros(0, bool), "locus_ok": np.ones(batch.n_loci, bool)}
+        tm["count_s"] += time.perf_counter() - t_a
+        t_a = time.perf_counter()
+        ok_items = np.nonzero(ok)[0]
+        for li, (locus, rd) in enumerate(live):
+            r0, r1 = int(batch.read_off[li]), int(batch.read_off[li + 1])
+            kept = [r for r in range(r0, r1) if flt["keep"][r]]
+            reads = {}
+            for r in kept:
+                it = int(ok_items[r])
+                ri = int(rec[it])
+                sc = float(flt["sc"][r])
+                reads[bam.name(ri)] = {"s": bam.strand(ri), "cn": int(res["cn"][r]), "w": 1.0 / len(kept),
+                                       "sc": None if np.isnan(sc) else sc, "sl": int(batch.ntr[r]),
+                                       **({"realn": True} if alt and it in alt else {})}
+            row = _locus_dict(locus)
+            row["ref_cn"] = int(rd["ref_cn"])
+            if not respect_ref:
+                row["start_adj"], row["end_adj"] = rd["left_coord_adj"], rd["right_coord_adj"]
+            row["ref_start_anchor"] = rd["ref_left_flank_seq"][-VCF_ANCHOR_SIZE:].upper()
+            row["peaks"], row["read_peaks_called"] = None, False
+            row["reads"] = reads if flt["locus_ok"][li] else {}
+            n_depth += len(row["reads"])
+            results.append(row)
+        tm["extract_s"] += time.perf_counter() - t_a
     results.sort(key=lambda r: r["locus_index"])
     return results, n_depth, tm
 

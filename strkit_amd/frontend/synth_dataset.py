@@ -29,42 +29,54 @@ def _motif(rng, lo, hi) -> str:
 
 def _sequence_read(rng, hap: str, ops_ref: list[tuple[int, str]], sub: float, indel: float):
     """Apply per-base errors to `hap` whose alignment to the reference is `ops_ref` (run-length list over hap/ref
-    columns: '=' match run, 'I' bases only in hap, 'D' bases only in ref).  Returns (read, cigar runs)."""
+    columns: '=' match run, 'I' bases only in hap, 'D' bases only in ref).  Returns (read, cigar runs).
+    Error positions are drawn first (a handful per read at HiFi rates), the read is assembled from the slices
+    between them."""
+    n = len(hap)
+    ev = {}
+    if sub > 0 or indel > 0:
+        x = rng.random(n)
+        for p in np.nonzero(x < sub + indel)[0]:
+            ev[int(p)] = 0 if x[p] < sub else (1 if x[p] < sub + indel / 2 else 2)   # 0 sub, 1 deletion, 2 insertion
     out, cig = [], []
 
-    def push(op, n=1):
-        if n <= 0:
+    def push(op, k=1):
+        if k <= 0:
             return
         if cig and cig[-1][1] == op:
-            cig[-1][0] += n
+            cig[-1][0] += k
         else:
-            cig.append([n, op])
+            cig.append([k, op])
 
+    keys = sorted(ev)
+    ki = 0
     pos = 0
     for ln, op in ops_ref:
         if op == "D":
             push("D", ln)
             continue
-        for _ in range(ln):
-            ch = hap[pos]
+        end = pos + ln
+        while pos < end:
+            nxt = keys[ki] if ki < len(keys) and keys[ki] < end else end
+            if nxt > pos:                       # clean stretch
+                out.append(hap[pos:nxt])
+                push(op, nxt - pos)
+                pos = nxt
+                continue
+            ch, kind = hap[pos], ev[pos]
+            ki += 1
             pos += 1
-            x = rng.random()
-            if x < sub:
-                alt = "ACGT".replace(ch, "")[int(rng.integers(3))]
-                out.append(alt)
+            if kind == 0:
+                out.append("ACGT".replace(ch, "")[int(rng.integers(3))])
                 push("X" if op == "=" else "I")
-            elif x < sub + indel / 2:
+            elif kind == 1:
                 if op == "=":
-                    push("D")             # base missing from the read
-            elif x < sub + indel:
-                out.append(ch)
-                push(op)
-                out.append("ACGT"[int(rng.integers(4))])
-                push("I")
+                    push("D")                   # base missing from the read
             else:
-                out.append(ch)
+                out.append(ch + "ACGT"[int(rng.integers(4))])
                 push(op)
-    return "".join(out), [(n, o) for n, o in cig]
+                push("I")
+    return "".join(out), [(k, o) for k, o in cig]
 
 
 def make_dataset(out_dir: str, n_loci: int = 20, reads_per_locus: int = 12, read_len: int = 3000, seed: int = 7,

@@ -152,3 +152,48 @@ def test_cigar_run_lookup_equals_expanded_pairs(tmp_path):
                 assert a == b, (s.name, shift)
                 n += not a.is_incomplete()
     assert n > 100
+
+
+def test_native_scan_and_extraction_equal_the_python_statement(tmp_path):
+    """strk_bam_scan / strk_extract_reads (C++, host only) against bam.py / extract.py, record by record."""
+    from strkit_amd.frontend import NativeBam, extract_reads, get_read_coords_from_cigar
+    t = make_dataset(str(tmp_path), n_loci=12, reads_per_locus=10, read_len=1500, seed=4, sub=0.01, indel=0.02,
+                     low_qual=0.02, soft_clip_frac=0.3, expansion=15)
+    nb, pb = NativeBam(t["paths"]["bam"]), read_bam(t["paths"]["bam"])
+    assert nb.n_records == len(pb.segments) == 120 and nb.references == pb.references
+    (block,) = load_loci(t["paths"]["loci"])
+    seen = np.zeros(3, int)
+    for locus in block:
+        idx = nb.fetch_indices(locus.contig, locus.left_flank_coord, locus.right_flank_coord)
+        segs = pb.fetch(locus.contig, locus.left_flank_coord, locus.right_flank_coord)
+        assert [nb.name(i) for i in idx] == [s.name for s in segs]
+        assert nb.soft_clip_overlaps(idx, locus.left_flank_coord, locus.right_flank_coord).tolist() == \
+            [s.soft_clip_overlaps_locus(locus) for s in segs]
+        coords = np.tile([locus.left_flank_coord, locus.left_coord, locus.right_coord, locus.right_flank_coord], (len(idx), 1))
+        ex = extract_reads(nb, idx, coords, 70, 13)
+        for k, s in enumerate(segs):
+            s2 = nb.segment(int(idx[k]))
+            assert (s2.query_sequence, s2.start, s2.end, s2.flag) == (s.query_sequence, s.start, s.end, s.flag)
+            assert np.array_equal(s2.cigar, s.cigar) and np.array_equal(s2.query_qualities, s.query_qualities)
+            c = get_read_coords_from_cigar(locus.left_flank_coord, locus.left_coord, locus.right_coord, locus.right_flank_coord, s)
+            seen[ex["status"][k]] += 1
+            if c.is_incomplete():
+                assert ex["status"][k] == 1
+                continue
+            try:
+                sd = get_sequence_data_for_locus(s, c, 70)
+            except LowMeanBaseQual:
+                assert ex["status"][k] == 2
+                continue
+            fl, tr, fr = sd.flank_left_seq_wc[-70:], sd.tr_seq_wc, sd.flank_right_seq_wc[:70]
+            assert ex["status"][k] == 0 and (ex["nfl"][k], ex["ntr"][k], ex["nfr"][k]) == (len(fl), len(tr), len(fr))
+            assert ex["seqs"][ex["seq_off"][k]:ex["seq_off"][k + 1]].tobytes().decode() == fl + tr + fr
+    assert seen[0] > 50 and seen[1] > 5
+
+
+def test_realign_cigar_becomes_a_read_alignment():
+    from strkit_amd.frontend.native import realign_cigar_to_read_alignment
+    enc = {"M": 0, "I": 1, "D": 2, "S": 4, "=": 7, "X": 8}
+    mk = lambda runs: np.array([(n << 4) | enc[o] for n, o in runs], np.uint32)  # noqa: E731
+    got = realign_cigar_to_read_alignment(mk([(500, "D"), (70, "="), (12, "D"), (30, "="), (2, "I"), (40, "=")]))
+    assert got.tolist() == mk([(500, "S"), (70, "="), (12, "I"), (30, "="), (2, "D"), (40, "=")]).tolist()

@@ -7,7 +7,7 @@ import tempfile
 import time
 
 sys.path.insert(0, ".")
-from strkit_amd.frontend import Fasta, call_sample, read_bam  # noqa: E402
+from strkit_amd.frontend import Fasta, NativeBam, call_sample  # noqa: E402
 from strkit_amd.frontend.synth_dataset import make_dataset  # noqa: E402
 
 n_loci = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
@@ -17,7 +17,7 @@ d = tempfile.mkdtemp()
 t0 = time.perf_counter()
 truth = make_dataset(d, n_loci=n_loci, reads_per_locus=rpl, read_len=rlen, seed=1, sub=0.001, indel=0.002, low_qual=0.0005)
 t1 = time.perf_counter()
-bam = read_bam(truth["paths"]["bam"])
+bam = NativeBam(truth["paths"]["bam"])
 ref = Fasta(truth["paths"]["ref"])
 t2 = time.perf_counter()
 call_sample(bam, ref, truth["paths"]["loci"])          # warm-up (library load, workspaces)
