@@ -81,8 +81,8 @@ def cpu_baseline(cfg: int, sample_loci: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's own count)")
     ap.add_argument("--window", type=int, default=0)

@@ -37,6 +37,9 @@ thread_local std::string g_err;
 // device with others takes half the CU slots, so that the tail of one call and the head of the next co-run
 std::atomic<int> g_calls_in_flight{0};
 
+// consecutive default-window calls of this process without a window miss (negative: the wide window is enforced)
+std::atomic<int> g_win_quiet{0};
+
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -96,6 +99,7 @@ struct strk_ctx {
     size_t scratch_ints = 0;
     int band_cooldown = 0;   // > 0: the band kernel is switched off for that many calls (too many certificates failed)
     int band_penalty = 32;   // length of the next cool-down (doubles while retries keep failing)
+    bool p_window_auto = false;
     // work-queue lengths of the previous finished call (wave chunks), used to size the persistent grids of the
     // kernels that usually have little or nothing to do: an idle block still claims its 70-80 KB of LDS on a CU
     // and so delays the band blocks of the calls it overlaps with
@@ -115,6 +119,7 @@ namespace {
 using namespace strk;
 
 constexpr int kDefaultWindow = 8;
+constexpr int kQuietWindow = 6;    // default window of a context whose recent calls never left their windows
 // Scratch pool (int32 units): kLongWaves slots of kLongSlotInts for k_dp_long (one per resident wave; a slot
 // holds the backward row of all column tiles + two boundary columns: windows up to ~16 kb), then 16 Mi
 // ints of H rows for the generic kernel.  448 MiB of the 288 GB, allocated once per context.
@@ -531,6 +536,12 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     int rc;
     if ((rc = check_params(params, &p))) return rc;
     if (!b || b->n_reads < 0 || b->n_loci < 0) return fail(STRK_E_INVALID, "bad batch");
+    // default window: 8 sizes either side of the estimate; 6 once eight calls in a row (of this process: one sample,
+    // whatever context they ran on) stayed inside their windows.  A miss costs an extra round on the host, so a single
+    // one brings the wide window back for 64 calls.
+    c->p_window_auto = params->window <= 0;
+    if (c->p_window_auto && g_win_quiet.load(std::memory_order_relaxed) >= 8 && p.local_search_range + p.step_size + 2 <= kQuietWindow)
+        p.window = kQuietWindow;
     c->p_batch = *b;
     c->p_params = p;
     c->p_stream = st;
@@ -606,6 +617,10 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
     fprintf(stderr, "[phase ticks/64] header %d stage %d tables %d bwd %d fwd %d epilogue %d\n", c->h_counters[40], c->h_counters[41],
             c->h_counters[42], c->h_counters[43], c->h_counters[44], c->h_counters[45]);
 #endif
+    if (c->p_window_auto) {
+        if (c->h_counters[kCntMiss] > 0) g_win_quiet.store(-64, std::memory_order_relaxed);
+        else if (g_win_quiet.load(std::memory_order_relaxed) < (1 << 20)) g_win_quiet.fetch_add(1, std::memory_order_relaxed);
+    }
     {   // queue lengths of this call, for the grids of the next one (enqueue_scoring)
         int exact_chunks = 0, wide_chunks = 0;
         for (int k = 0; k < kNumClasses; ++k) {
