@@ -204,7 +204,7 @@ def main() -> None:
         FETCH_SIZE is doubled, the guide's gfx950 correction (calibrated here on k_hash, which reads every
         input byte exactly once: raw FETCH_SIZE = 0.49 x bytes)."""
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_e_pmc_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_f_pmc_summary.json")) as f:
                 k = json.load(f)[kernel]
             return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
         except Exception:  # noqa: BLE001

@@ -5,9 +5,9 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_bench
 mkdir -p $OUT
-ARGS="bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+ARGS="bench.py --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o b -- python3 $ARGS > $OUT/trace.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_p1 -o b -- python3 $ARGS --pipeline 1 --steps 20 --warmup 3 > $OUT/trace_p1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_p1 -o b -- python3 $ARGS --pipeline 1 --steps 40 --warmup 12 > $OUT/trace_p1.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$tag -o b -- python3 $ARGS > $OUT/pmc_$tag.log 2>&1 || echo "pmc $set failed"
