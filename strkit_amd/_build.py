@@ -15,8 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libstrkit_amd.so")
 SOURCES = ["strk_api.hip"]
-# every header under csrc/ (picked up by name, so that a new one can never be left out of the staleness hash) + the C ABI
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "strkit_amd.h")]
+# every header and include fragment under csrc/ (picked up by name, so that a new one can never be left out of the staleness hash) + the C ABI
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join("..", "..", "include", "strkit_amd.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-Wall", "-Wextra", "-Wno-unused-parameter"]
 

@@ -1,4 +1,7 @@
 // strk_api.hip — host side of libstrkit_amd.so (C ABI declared in include/strkit_amd.h).
+// The batched counting path is here; three parts live in include fragments that are spliced into this file's
+// anonymous namespace: strk_host_miss.inc (window-miss rounds), strk_host_ref.inc (reference side),
+// strk_host_realign.inc (realignment).  strk_frontend.h holds the CPU-only record scan / read extraction.
 //
 // One context = one HIP device.  A batched call enqueues, on the caller's stream:
 //   memset(counters) -> k_plan -> k_dp<class> x 13 -> k_dp_generic -> k_replay -> counters D2H
@@ -252,281 +255,7 @@ int check_error_bits(int bits) {
     return 0;
 }
 
-struct SeenVec {
-    std::vector<uint8_t> v;
-    bool test(int k) const { return v[(size_t)k] != 0; }
-    void set(int k) { v[(size_t)k] = 1; }
-};
-
-// Host-driven rounds for loci whose search left the speculative window.  Everything here works on
-// DEVICE batch pointers; host copies of the small metadata are fetched once.
-// Host copy of one locus that needs window-miss rounds: only the slices of its own reads are fetched.
-struct MissLocus {
-    int l = 0, r0 = 0, r1 = 0, m = 1;
-    int first = 0;                 // first read the host (re)plays
-    double frac = 0.0;
-    int32_t need_lo = 0, need_hi = 0;
-    std::vector<int32_t> est, win_lo, win_n, rep, nfl, ntr, nfr, table, o_cn, o_score, o_n, o_start, ext_lo;
-    std::vector<int64_t> tab_off;
-    std::vector<uint8_t> exact;
-    std::vector<std::vector<int32_t>> ext;   // exact, widened tables of re-scored reads
-};
-
-int resolve_misses(strk_ctx* c, const strk_batch* b, const strk_params& p, KArgs a, ReplayArgs rp, hipStream_t st,
-                   strk_stats* stats, int err_bits) {
-    const int nl = b->n_loci, ts = a.table_stride;
-    std::vector<int32_t> read_off(nl + 1), motif_off(nl + 1), next_read(nl), need_lo(nl), need_hi(nl);
-    std::vector<double> frac(nl);
-    HIP_TRY(hipMemcpy(read_off.data(), b->read_off, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(motif_off.data(), b->motif_off, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(next_read.data(), rp.next_read, (size_t)nl * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(need_lo.data(), rp.need_lo, (size_t)nl * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(need_hi.data(), rp.need_hi, (size_t)nl * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(frac.data(), rp.frac, (size_t)nl * 8, hipMemcpyDeviceToHost));
-
-    // Few loci with misses (the usual case): fetch only their slices.  Many (noisy reads whose banded tables cannot
-    // be certified from a different start): one bulk copy per array is cheaper than thirteen small ones per locus.
-    int n_pending = 0;
-    for (int l = 0; l < nl; ++l) n_pending += next_read[l] < read_off[l + 1];
-    const bool bulk = n_pending > 24;
-    const size_t nr = (size_t)b->n_reads;
-    std::vector<int32_t> m_est, m_win_lo, m_win_n, m_rep, m_nfl, m_ntr, m_nfr, m_cn, m_score, m_n, m_start, m_table;
-    std::vector<int64_t> m_tab_off;
-    std::vector<uint8_t> m_exact;
-    if (bulk) {
-        auto all32 = [&](std::vector<int32_t>& v, const int32_t* src, size_t cnt) {
-            v.resize(cnt);
-            return hipMemcpy(v.data(), src, cnt * 4, hipMemcpyDeviceToHost);
-        };
-        HIP_TRY(all32(m_est, b->est_cn, nr));
-        HIP_TRY(all32(m_win_lo, a.win_lo, nr));
-        HIP_TRY(all32(m_win_n, a.win_n, nr));
-        HIP_TRY(all32(m_rep, a.rep, nr));
-        HIP_TRY(all32(m_nfl, b->nfl, nr));
-        HIP_TRY(all32(m_ntr, b->ntr, nr));
-        HIP_TRY(all32(m_nfr, b->nfr, nr));
-        HIP_TRY(all32(m_cn, rp.out_cn, nr));
-        HIP_TRY(all32(m_score, rp.out_score, nr));
-        HIP_TRY(all32(m_n, rp.out_n, nr));
-        HIP_TRY(all32(m_start, rp.out_start, nr));
-        HIP_TRY(all32(m_table, a.table, nr * ts));
-        m_tab_off.resize(nr);
-        HIP_TRY(hipMemcpy(m_tab_off.data(), a.tab_off, nr * 8, hipMemcpyDeviceToHost));
-        if (a.band_mode) {
-            m_exact.resize(nr);
-            HIP_TRY(hipMemcpy(m_exact.data(), a.exact, nr, hipMemcpyDeviceToHost));
-        }
-    }
-    std::vector<MissLocus> loci;
-    loci.reserve((size_t)n_pending);
-    for (int l = 0; l < nl; ++l) {
-        if (next_read[l] >= read_off[l + 1]) continue;
-        MissLocus L;
-        L.l = l; L.r0 = read_off[l]; L.r1 = read_off[l + 1]; L.m = motif_off[l + 1] - motif_off[l];
-        L.first = next_read[l]; L.frac = frac[l]; L.need_lo = need_lo[l]; L.need_hi = need_hi[l];
-        const size_t n = (size_t)(L.r1 - L.r0);
-        auto get32 = [&](std::vector<int32_t>& v, const int32_t* src, const std::vector<int32_t>& mirror) {
-            if (bulk) {
-                v.assign(mirror.begin() + L.r0, mirror.begin() + L.r1);
-                return hipSuccess;
-            }
-            v.resize(n);
-            return hipMemcpy(v.data(), src + L.r0, n * 4, hipMemcpyDeviceToHost);
-        };
-        HIP_TRY(get32(L.est, b->est_cn, m_est));
-        HIP_TRY(get32(L.win_lo, a.win_lo, m_win_lo));
-        HIP_TRY(get32(L.win_n, a.win_n, m_win_n));
-        HIP_TRY(get32(L.rep, a.rep, m_rep));
-        HIP_TRY(get32(L.nfl, b->nfl, m_nfl));
-        HIP_TRY(get32(L.ntr, b->ntr, m_ntr));
-        HIP_TRY(get32(L.nfr, b->nfr, m_nfr));
-        HIP_TRY(get32(L.o_cn, rp.out_cn, m_cn));
-        HIP_TRY(get32(L.o_score, rp.out_score, m_score));
-        HIP_TRY(get32(L.o_n, rp.out_n, m_n));
-        HIP_TRY(get32(L.o_start, rp.out_start, m_start));
-        L.exact.assign(n, 1);
-        // copies of a read share the table slot of their first occurrence, which lies in the same locus
-        if (bulk) {
-            L.tab_off.assign(m_tab_off.begin() + L.r0, m_tab_off.begin() + L.r1);
-            if (a.band_mode) L.exact.assign(m_exact.begin() + L.r0, m_exact.begin() + L.r1);
-            L.table.assign(m_table.begin() + (size_t)L.r0 * ts, m_table.begin() + (size_t)L.r1 * ts);
-        } else {
-            L.tab_off.resize(n);
-            HIP_TRY(hipMemcpy(L.tab_off.data(), a.tab_off + L.r0, n * 8, hipMemcpyDeviceToHost));
-            if (a.band_mode) HIP_TRY(hipMemcpy(L.exact.data(), a.exact + L.r0, n, hipMemcpyDeviceToHost));
-            L.table.resize(n * ts);
-            HIP_TRY(hipMemcpy(L.table.data(), a.table + (size_t)L.r0 * ts, n * ts * 4, hipMemcpyDeviceToHost));
-        }
-        L.ext.resize(n);
-        L.ext_lo.assign(n, 0);
-        loci.push_back(std::move(L));
-    }
-
-    std::vector<MissLocus*> pending;
-    for (auto& L : loci) pending.push_back(&L);
-    int rounds = 0, miss_reads = 0, rc;
-    if ((rc = c->win_lo2.ensure((size_t)b->n_reads * 4))) return rc;
-    if ((rc = c->win_n2.ensure((size_t)b->n_reads * 4))) return rc;
-    if ((rc = c->tab_off2.ensure((size_t)b->n_reads * 8))) return rc;
-    while (!pending.empty()) {
-        if (++rounds > 4096) return fail(STRK_E_DEVICE, "window-miss resolution did not converge");
-        // 1. windows wanted this round: one read per pending locus
-        std::vector<int32_t> items, w_lo, w_n;
-        std::vector<int64_t> w_off;
-        size_t tab2 = 0, n_chunks = 0;
-        for (MissLocus* L : pending) {
-            const int k = L->first - L->r0;
-            const bool has_ext = !L->ext[k].empty();
-            const int64_t cur_lo = has_ext ? L->ext_lo[k] : L->win_lo[k];
-            const int64_t cur_hi = cur_lo + (has_ext ? (int64_t)L->ext[k].size() : L->win_n[k]) - 1;
-            const int64_t lo2 = std::min<int64_t>(cur_lo, std::max<int64_t>(0, (int64_t)L->need_lo - p.window));
-            const int64_t hi2 = std::max<int64_t>(cur_hi, (int64_t)L->need_hi + p.window);
-            if (hi2 - lo2 + 1 > (int64_t)1 << 20) return fail(STRK_E_INVALID, "candidate window grew past 2^20 sizes");
-            items.push_back(L->first);
-            w_lo.push_back((int32_t)lo2);
-            w_n.push_back((int32_t)(hi2 - lo2 + 1));
-            w_off.push_back((int64_t)tab2);
-            tab2 += (size_t)(hi2 - lo2 + 1);
-            n_chunks += ((size_t)(hi2 - lo2 + 1) + kTableMax - 1) / kTableMax;
-            ++miss_reads;
-        }
-        // 2. score them exactly on the device (per-read window arrays are patched entry by entry)
-        if ((rc = c->table2.ensure(tab2 * 4))) return rc;
-        if ((rc = c->items.ensure(items.size() * 4))) return rc;
-        if ((rc = c->cls_list.ensure((size_t)kNumLists * n_chunks * 2 * 4))) return rc;
-        std::vector<int32_t> f_lo, f_n;   // full-size images when many reads are re-scored (must outlive the copies)
-        std::vector<int64_t> f_off;
-        if (items.size() > 48) {
-            f_lo.assign(nr, 0);
-            f_n.assign(nr, 0);
-            f_off.assign(nr, 0);
-            for (size_t i = 0; i < items.size(); ++i) {
-                const size_t r = (size_t)items[i];
-                f_lo[r] = w_lo[i];
-                f_n[r] = w_n[i];
-                f_off[r] = w_off[i];
-            }
-            HIP_TRY(hipMemcpyAsync(c->win_lo2.p, f_lo.data(), nr * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(c->win_n2.p, f_n.data(), nr * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(c->tab_off2.p, f_off.data(), nr * 8, hipMemcpyHostToDevice, st));
-        } else {
-            for (size_t i = 0; i < items.size(); ++i) {
-                const size_t r = (size_t)items[i];
-                HIP_TRY(hipMemcpyAsync(c->win_lo2.as<int32_t>() + r, &w_lo[i], 4, hipMemcpyHostToDevice, st));
-                HIP_TRY(hipMemcpyAsync(c->win_n2.as<int32_t>() + r, &w_n[i], 4, hipMemcpyHostToDevice, st));
-                HIP_TRY(hipMemcpyAsync(c->tab_off2.as<int64_t>() + r, &w_off[i], 8, hipMemcpyHostToDevice, st));
-            }
-        }
-        HIP_TRY(hipMemcpyAsync(c->items.p, items.data(), items.size() * 4, hipMemcpyHostToDevice, st));
-        KArgs a2 = a;
-        a2.win_lo = c->win_lo2.as<int32_t>();
-        a2.win_n = c->win_n2.as<int32_t>();
-        a2.tab_off = c->tab_off2.as<int64_t>();
-        a2.table = c->table2.as<int32_t>();
-        a2.cls_list = c->cls_list.as<int32_t>();
-        a2.list_stride = (int32_t)n_chunks;
-        a2.spec = nullptr;
-        a2.band_mode = 0;   // window-miss rounds always score exactly
-        a2.exact = nullptr;
-        HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
-        enqueue_scoring(c, a2, 1, c->items.as<int32_t>(), (int)items.size(), 0, st, false);
-        HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
-        std::vector<int32_t> t2(tab2);
-        HIP_TRY(hipMemcpyAsync(t2.data(), c->table2.p, tab2 * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipGetLastError());
-        if ((rc = check_error_bits(c->h_counters[kCntError] & ~kErrEmpty))) return rc;
-        if (stats) {
-            stats->n_fallback += c->h_counters[kCntClass0 + kGenericClass];
-            stats->dp_cells += (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
-        }
-        for (size_t i = 0; i < pending.size(); ++i) {
-            MissLocus* L = pending[i];
-            const int k = L->first - L->r0;
-            L->ext_lo[k] = w_lo[i];
-            L->ext[k].assign(t2.begin() + w_off[i], t2.begin() + w_off[i] + w_n[i]);
-        }
-        // 3. replay the pending loci on the host until the next miss
-        std::vector<MissLocus*> still;
-        for (MissLocus* L : pending) {
-            int r = L->first;
-            double fr = L->frac;
-            bool missed = false;
-            for (; r < L->r1; ++r) {
-                const int k = r - L->r0;
-                int start = L->est[k];
-                double fr_try = fr;
-                if (p.feedback) start = feedback_start(L->est[k], &fr_try);
-                const bool use_ext = !L->ext[k].empty();
-                const int32_t* sc = use_ext ? L->ext[k].data() : L->table.data() + (L->tab_off[k] - (int64_t)L->r0 * ts);
-                const int32_t lo = use_ext ? L->ext_lo[k] : L->win_lo[k];
-                const int32_t n = use_ext ? (int32_t)L->ext[k].size() : L->win_n[k];
-                SeenVec seen;
-                seen.v.assign((size_t)std::max(n, 1), 0);
-                SearchResult res;
-                const int rpk = L->rep[k] - L->r0;   // first occurrence of this read's bytes (same locus)
-                if (use_ext || !a.band_mode || L->exact[rpk]) {
-                    res = search_replay(start, p.step_size, p.local_search_range, p.max_iters, p.tie_rule == STRK_TIE_LAST, sc,
-                                        lo, n, seen);
-                } else {   // banded table of the device pass: same certified search as k_replay
-                    const BandGeo geo = band_geometry(L->nfl[rpk], L->ntr[rpk], L->nfr[rpk], L->m, lo, n);
-                    auto ub = [&](int kk) { return band_ub(geo, L->nfl[rpk], L->ntr[rpk], L->nfr[rpk], L->m, lo + kk, p.end_flags); };
-                    const CertResult cr = search_replay_cert(start, p.step_size, p.local_search_range, p.max_iters,
-                                                             p.tie_rule == STRK_TIE_LAST, sc, lo, n, seen, ub);
-                    res = cr.res;
-                    if (cr.uncertain) { res.miss = 1; res.need_lo = lo; res.need_hi = lo + n - 1; }
-                }
-                if (res.miss) {
-                    L->need_lo = res.need_lo;
-                    L->need_hi = res.need_hi;
-                    missed = true;
-                    break;
-                }
-                fr = fr_try;
-                L->o_start[k] = start;
-                L->o_n[k] = res.n_explored;
-                if (res.empty) {
-                    L->o_cn[k] = 0; L->o_score[k] = 0;
-                    err_bits |= kErrEmpty;
-                    continue;
-                }
-                L->o_cn[k] = res.cn;
-                L->o_score[k] = res.score;
-                if (p.feedback) feedback_update(&fr, res.cn, start);
-            }
-            L->first = r;
-            L->frac = fr;
-            if (missed) still.push_back(L);
-        }
-        pending.swap(still);
-    }
-    if (bulk) {   // write back through the full-size images
-        for (auto& L : loci) {
-            std::copy(L.o_cn.begin(), L.o_cn.end(), m_cn.begin() + L.r0);
-            std::copy(L.o_score.begin(), L.o_score.end(), m_score.begin() + L.r0);
-            std::copy(L.o_n.begin(), L.o_n.end(), m_n.begin() + L.r0);
-            std::copy(L.o_start.begin(), L.o_start.end(), m_start.begin() + L.r0);
-        }
-        HIP_TRY(hipMemcpyAsync(rp.out_cn, m_cn.data(), nr * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(rp.out_score, m_score.data(), nr * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(rp.out_n, m_n.data(), nr * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(rp.out_start, m_start.data(), nr * 4, hipMemcpyHostToDevice, st));
-    } else {
-        for (auto& L : loci) {   // write back the reads the host finished
-            const size_t n = (size_t)(L.r1 - L.r0);
-            HIP_TRY(hipMemcpyAsync(rp.out_cn + L.r0, L.o_cn.data(), n * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(rp.out_score + L.r0, L.o_score.data(), n * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(rp.out_n + L.r0, L.o_n.data(), n * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(rp.out_start + L.r0, L.o_start.data(), n * 4, hipMemcpyHostToDevice, st));
-        }
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    if (stats) {
-        stats->n_miss_reads = miss_reads;
-        stats->n_miss_rounds = rounds;
-    }
-    return check_error_bits(err_bits);
-}
+#include "strk_host_miss.inc"
 
 // Enqueue one batched call on `st` and return without waiting.
 int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, int32_t* out_cn, int32_t* out_score,
@@ -782,427 +511,9 @@ int score_table_impl(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, 
 // Lazily scored (fwd score, fwd end_query, rev score, rev end_query) per candidate size for one locus:
 // two device "reads" — the window itself and its reversal with the flanks swapped
 // (repeats.py:32-41: ext_l_seq = (tr_candidate + flank_right_seq)[::-1] against db_seq[::-1]).
-// One locus of the reference-side path (get_ref_repeat_count, strkit/call/repeats.py:73-192).  The search runs on
-// the host over (score, end_query) pairs the device computes; a job whose search meets a size that has not been
-// scored yet reports the window it needs and is re-run from the start once the batch of all such windows is back.
-struct RefJob {
-    int32_t start = 0, nfl = 0, ntr = 0, nfr = 0, m = 1, ref_size = 0, max_iters = 0, lsr = 0, step = 1;
-    std::vector<uint8_t> db, motif;             // fl|tr|fr and the motif, as given
-    std::vector<int64_t> sizes;                 // scored sizes (unordered)
-    std::vector<std::array<int32_t, 4>> vals;   // fwd score, fwd end_query, rev score, rev end_query
-    int32_t l_offset = 0, r_offset = 0, n_off = 0;
-    int64_t need_lo = 0, need_hi = -1;
-    int find(int64_t i) const {
-        for (size_t k = 0; k < sizes.size(); ++k)
-            if (sizes[k] == i) return (int)k;
-        return -1;
-    }
-    bool has_all(int64_t w_lo, int64_t w_hi) const {
-        for (int64_t i = w_lo; i <= w_hi; ++i)
-            if (find(i) < 0) return false;
-        return true;
-    }
-};
+#include "strk_host_ref.inc"
 
-// Boundary-extension search of one job on its cached scores.  Returns 1 when finished (offsets set), 0 when it
-// needs sizes [need_lo, need_hi] scored first, < 0 on error.
-int ref_search(RefJob& j, int32_t vcf_anchor_size) {
-    const int32_t nfl = j.nfl, nfr = j.nfr, step = j.step, lsr = j.lsr;
-    // dicts in insertion order (repeats.py:103-104); fwd and rev are always filled together (:123-128)
-    std::vector<int64_t> key;
-    std::vector<int32_t> fs, fa, rs, ra;
-    auto find_key = [&](int64_t i) {
-        for (size_t k = 0; k < key.size(); ++k)
-            if (key[k] == i) return (int)k;
-        return -1;
-    };
-    int64_t st_size[4];
-    int32_t st_dir[4];
-    int sp = 0, n_off = 0;
-    st_size[sp] = (int64_t)j.start - step; st_dir[sp++] = -1;   // :100-101
-    st_size[sp] = (int64_t)j.start + step; st_dir[sp++] = 1;
-    st_size[sp] = j.start;                 st_dir[sp++] = 0;
-    const bool widen = step > lsr;
-    while (sp > 0 && n_off < j.max_iters) {                                  // :106
-        --sp;
-        const int64_t size = st_size[sp];
-        const int32_t dir = st_dir[sp];
-        if (size < 0) continue;                                              // :108-109
-        int64_t w_lo = size - ((dir < 1 || widen) ? lsr : 0);                // :114-117
-        if (w_lo < 0) w_lo = 0;
-        const int64_t w_hi = size + ((dir > -1 || widen) ? lsr : 0);
-        if (!j.has_all(w_lo, w_hi)) {
-            j.need_lo = w_lo;
-            j.need_hi = w_hi;
-            return 0;
-        }
-        for (int64_t i = w_lo; i <= w_hi; ++i) {                             // :119-130
-            if (find_key(i) >= 0) continue;
-            const auto& v = j.vals[(size_t)j.find(i)];
-            key.push_back(i);
-            fs.push_back(v[0]); fa.push_back(v[1] + 1 - nfl - j.ref_size);   // :34
-            rs.push_back(v[2]); ra.push_back(v[3] + 1 - nfr - j.ref_size);   // :41
-            ++n_off;
-        }
-        // mv = max((*fwd_scores, *rev_scores), key=(score, adj)): first maximum of the concatenation (:135)
-        bool have = false;
-        int64_t mv_i = 0;
-        int32_t mv_s = 0, mv_a = 0;
-        for (int pass = 0; pass < 2; ++pass)
-            for (int64_t i = w_lo; i <= w_hi; ++i) {
-                const int at = find_key(i);
-                const int32_t sc = pass == 0 ? fs[(size_t)at] : rs[(size_t)at];
-                const int32_t ad = pass == 0 ? fa[(size_t)at] : ra[(size_t)at];
-                if (!have || sc > mv_s || (sc == mv_s && ad > mv_a)) { have = true; mv_i = i; mv_s = sc; mv_a = ad; }
-            }
-        if (mv_i > size && find_key(mv_i + step) < 0 && mv_i + step >= 0) { st_size[sp] = mv_i + step; st_dir[sp++] = 1; }    // :136-143
-        if (mv_i < size && find_key(mv_i - step) < 0 && mv_i - step >= 0) { st_size[sp] = mv_i - step; st_dir[sp++] = -1; }  // :144-151
-    }
-    if (key.empty()) return fail(STRK_E_EMPTY, "max() arg is an empty sequence: no reference boundary could be scored");
-    size_t bf = 0, br = 0;                                                   // :154-156 first maxima by score
-    for (size_t k = 1; k < key.size(); ++k) {
-        if (fs[k] > fs[bf]) bf = k;
-        if (rs[k] > rs[br]) br = k;
-    }
-    j.l_offset = ra[br];                                                     // :161-162
-    j.r_offset = fa[bf];
-    if (j.l_offset >= nfl - vcf_anchor_size) j.l_offset = 0;                 // :164-169
-    if (j.r_offset >= nfr) j.r_offset = 0;
-    j.n_off = n_off;
-    return 1;
-}
-
-// Scores the requested windows of `req` jobs in ONE device call: two windows per job (the window and its
-// reversal with the flanks swapped, repeats.py:36-41), each against its own motif.
-int ref_score_requests(strk_ctx* ctx, std::vector<RefJob*>& req) {
-    const size_t nj = req.size();
-    std::vector<uint8_t> seqs, motifs;
-    std::vector<int64_t> seq_off{0}, toff{0};
-    std::vector<int32_t> nfl, ntr, nfr, read_off{0}, motif_off{0}, los, ns;
-    for (RefJob* j : req) {
-        const int64_t pad = j->step == 1 ? 8 : 0;   // dense look-ahead only pays for unit steps
-        const int64_t lo = std::max<int64_t>(0, j->need_lo - pad), hi = j->need_hi + pad;
-        if (hi - lo + 1 > 4096) return fail(STRK_E_INVALID, "reference-side window too wide");
-        const int32_t ndb = (int32_t)j->db.size();
-        for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 0) {
-                seqs.insert(seqs.end(), j->db.begin(), j->db.end());
-                motifs.insert(motifs.end(), j->motif.begin(), j->motif.end());
-            } else {
-                seqs.insert(seqs.end(), j->db.rbegin(), j->db.rend());
-                motifs.insert(motifs.end(), j->motif.rbegin(), j->motif.rend());
-            }
-            seq_off.push_back(seq_off.back() + ndb);
-            nfl.push_back(pass == 0 ? j->nfl : j->nfr);   // reversed window: the right flank leads
-            ntr.push_back(j->ntr);
-            nfr.push_back(pass == 0 ? j->nfr : j->nfl);
-            read_off.push_back(read_off.back() + 1);
-            motif_off.push_back(motif_off.back() + j->m);
-            los.push_back((int32_t)lo);
-            ns.push_back((int32_t)(hi - lo + 1));
-            toff.push_back(toff.back() + (hi - lo + 1));
-        }
-    }
-    std::vector<int32_t> sc((size_t)toff.back()), eq((size_t)toff.back());
-    strk_batch b;
-    b.n_reads = (int32_t)(2 * nj); b.n_loci = (int32_t)(2 * nj);
-    b.seqs = seqs.data(); b.seq_off = seq_off.data(); b.nfl = nfl.data(); b.ntr = ntr.data(); b.nfr = nfr.data();
-    b.est_cn = nullptr; b.read_off = read_off.data(); b.motifs = motifs.data(); b.motif_off = motif_off.data();
-    const int rc = score_table_impl(ctx, &b, los.data(), ns.data(), toff.data(), STRK_DB_END_FREE, 0, 1, sc.data(), eq.data(), nullptr);
-    if (rc) return rc;
-    for (size_t q = 0; q < nj; ++q) {
-        RefJob* j = req[q];
-        const int32_t lo = los[2 * q], n = ns[2 * q];
-        const int64_t f0 = toff[2 * q], r0 = toff[2 * q + 1];
-        for (int32_t k = 0; k < n; ++k) {
-            if (j->find((int64_t)lo + k) >= 0) continue;
-            j->sizes.push_back((int64_t)lo + k);
-            j->vals.push_back({sc[(size_t)f0 + k], eq[(size_t)f0 + k], sc[(size_t)r0 + k], eq[(size_t)r0 + k]});
-        }
-    }
-    return 0;
-}
-
-// get_ref_repeat_count for a batch of loci: boundary-extension searches in lock-step rounds (one device call per
-// round for all loci that still need scores), then the final read-style counts of all loci in one call per
-// distinct search schedule.  out9[9*i ..] as strk_ref_repeat_count.
-int ref_repeat_count_batch_impl(strk_ctx* ctx, std::vector<RefJob>& jobs, int32_t vcf_anchor_size, int32_t respect_coords,
-                                int32_t* out9) {
-    if (!respect_coords) {
-        std::vector<RefJob*> pending;
-        for (auto& j : jobs) pending.push_back(&j);
-        for (int round = 0; !pending.empty(); ++round) {
-            if (round > 4096) return fail(STRK_E_DEVICE, "reference-side search did not converge");
-            std::vector<RefJob*> req;
-            for (RefJob* j : pending) {
-                const int r = ref_search(*j, vcf_anchor_size);
-                if (r < 0) return r;
-                if (r == 0) req.push_back(j);
-            }
-            if (req.empty()) break;
-            const int rc = ref_score_requests(ctx, req);
-            if (rc) return rc;
-            pending.swap(req);
-        }
-    }
-    // final counts on the adjusted flank / tract split (repeats.py:171-188), grouped by search schedule
-    const size_t nj = jobs.size();
-    std::vector<int32_t> nfl2(nj), ntr2(nj), nfr2(nj), start2(nj);
-    for (size_t i = 0; i < nj; ++i) {
-        const RefJob& j = jobs[i];
-        const int32_t lo_pos = j.l_offset > 0 ? j.l_offset : 0, ro_pos = j.r_offset > 0 ? j.r_offset : 0;   // :171-176
-        nfl2[i] = j.nfl - lo_pos; ntr2[i] = j.ntr + lo_pos + ro_pos; nfr2[i] = j.nfr - ro_pos;
-        if (nfl2[i] < 0 || nfr2[i] < 0) return fail(STRK_E_INVALID, "boundary offsets exceed the flanks");
-        // round(((start * motif_size) + max(0, l) + max(0, r)) / motif_size): true division, round-half-even (:182)
-        start2[i] = (int32_t)__builtin_rint((double)((int64_t)j.start * j.m + lo_pos + ro_pos) / (double)j.m);
-    }
-    std::vector<char> done(nj, 0);
-    for (size_t g = 0; g < nj; ++g) {
-        if (done[g]) continue;
-        std::vector<size_t> grp;
-        for (size_t i = g; i < nj; ++i)
-            if (!done[i] && jobs[i].max_iters == jobs[g].max_iters && jobs[i].lsr == jobs[g].lsr && jobs[i].step == jobs[g].step) {
-                grp.push_back(i);
-                done[i] = 1;
-            }
-        std::vector<uint8_t> seqs, motifs;
-        std::vector<int64_t> seq_off{0};
-        std::vector<int32_t> a_nfl, a_ntr, a_nfr, a_est, read_off{0}, motif_off{0};
-        for (size_t i : grp) {
-            seqs.insert(seqs.end(), jobs[i].db.begin(), jobs[i].db.end());
-            motifs.insert(motifs.end(), jobs[i].motif.begin(), jobs[i].motif.end());
-            seq_off.push_back(seq_off.back() + (int64_t)jobs[i].db.size());
-            a_nfl.push_back(nfl2[i]); a_ntr.push_back(ntr2[i]); a_nfr.push_back(nfr2[i]); a_est.push_back(start2[i]);
-            read_off.push_back(read_off.back() + 1);
-            motif_off.push_back(motif_off.back() + jobs[i].m);
-        }
-        strk_batch b;
-        b.n_reads = (int32_t)grp.size(); b.n_loci = (int32_t)grp.size();
-        b.seqs = seqs.data(); b.seq_off = seq_off.data(); b.nfl = a_nfl.data(); b.ntr = a_ntr.data(); b.nfr = a_nfr.data();
-        b.est_cn = a_est.data(); b.read_off = read_off.data(); b.motifs = motifs.data(); b.motif_off = motif_off.data();
-        strk_params p;
-        memset(&p, 0, sizeof p);
-        p.max_iters = jobs[g].max_iters; p.local_search_range = jobs[g].lsr; p.step_size = jobs[g].step;
-        p.tie_rule = STRK_TIE_FIRST; p.end_flags = STRK_SG_ALL; p.feedback = 0;
-        p.window = std::min(15, std::max(kDefaultWindow, jobs[g].lsr + jobs[g].step + 1));   // as strk_repeat_count
-        std::vector<int32_t> cn(grp.size()), sc(grp.size()), ni(grp.size());
-        const int rc = strk_count_loci(ctx, &b, &p, cn.data(), sc.data(), ni.data(), nullptr, nullptr);
-        if (rc) return rc;
-        for (size_t q = 0; q < grp.size(); ++q) {
-            const size_t i = grp[q];
-            int32_t* o = out9 + 9 * i;
-            o[0] = cn[q]; o[1] = sc[q]; o[2] = jobs[i].l_offset; o[3] = jobs[i].r_offset; o[4] = jobs[i].n_off; o[5] = ni[q];
-            o[6] = nfl2[i]; o[7] = ntr2[i]; o[8] = nfr2[i];
-        }
-    }
-    return 0;
-}
-
-void ref_job_init(RefJob& j, int32_t start, const uint8_t* tr, int32_t ntr, const uint8_t* fl, int32_t nfl, const uint8_t* fr,
-                  int32_t nfr, const uint8_t* motif, int32_t m, int32_t ref_size, int32_t max_iters, int32_t lsr, int32_t step) {
-    j.start = start; j.nfl = nfl; j.ntr = ntr; j.nfr = nfr; j.m = m; j.ref_size = ref_size;
-    j.max_iters = max_iters; j.lsr = lsr; j.step = step;
-    j.db.resize((size_t)nfl + ntr + nfr);
-    if (nfl) memcpy(j.db.data(), fl, (size_t)nfl);
-    if (ntr) memcpy(j.db.data() + nfl, tr, (size_t)ntr);
-    if (nfr) memcpy(j.db.data() + nfl + ntr, fr, (size_t)nfr);
-    j.motif.assign(motif, motif + m);
-}
-
-// get_ref_repeat_count (strkit/call/repeats.py:73-192) for one locus: a batch of one.
-int ref_repeat_count_impl(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int32_t ntr, const uint8_t* fl,
-                          int32_t nfl, const uint8_t* fr, int32_t nfr, const uint8_t* motif, int32_t m, int32_t ref_size,
-                          int32_t vcf_anchor_size, int32_t max_iters, int32_t lsr, int32_t step, int32_t respect_coords,
-                          int32_t* out9) {
-    std::vector<RefJob> jobs(1);
-    ref_job_init(jobs[0], start_count, tr, ntr, fl, nfl, fr, nfr, motif, m, ref_size, max_iters, lsr, step);
-    return ref_repeat_count_batch_impl(ctx, jobs, vcf_anchor_size, respect_coords, out9);
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Realignment: strk_realign (strkit/call/realign.py:56-72)
-// ---------------------------------------------------------------------------------------------
-// Launches the DP kernel of one column class on pairs [first, first + count) of a.pairs (persistent grid).
-template <int CL, bool EXT0>
-void launch_realign_dp_t(const RealignArgs& a, int first, int count, int qslot, int device) {
-    static int resident = 0;   // blocks that fit the device (queried once per instantiation)
-    if (resident == 0) {
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_realign_dp<CL, EXT0>, 256, 0) != hipSuccess) per_cu = 1;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
-        resident = std::max(1, per_cu) * std::max(1, cus);
-    }
-    const int blocks = std::min(resident, (count + 3) / 4);
-    hipLaunchKernelGGL((k_realign_dp<CL, EXT0>), dim3(blocks), dim3(256), 0, nullptr, a, first, count, qslot);
-}
-void launch_realign_dp(int cl, bool ext0, const RealignArgs& a, int first, int count, int qslot, int device) {
-    switch (cl) {
-        case 4: ext0 ? launch_realign_dp_t<4, true>(a, first, count, qslot, device) : launch_realign_dp_t<4, false>(a, first, count, qslot, device); break;
-        case 8: ext0 ? launch_realign_dp_t<8, true>(a, first, count, qslot, device) : launch_realign_dp_t<8, false>(a, first, count, qslot, device); break;
-        case 16: ext0 ? launch_realign_dp_t<16, true>(a, first, count, qslot, device) : launch_realign_dp_t<16, false>(a, first, count, qslot, device); break;
-        default: ext0 ? launch_realign_dp_t<32, true>(a, first, count, qslot, device) : launch_realign_dp_t<32, false>(a, first, count, qslot, device); break;
-    }
-}
-
-int realign_impl(strk_ctx* c, int32_t n_pairs, const uint8_t* s1, const int64_t* s1_off, const uint8_t* s2,
-                 const int64_t* s2_off, int32_t open, int32_t ext, int32_t gap_pref, int32_t* out_score,
-                 int32_t* out_end_ref, int32_t* out_n_cigar, uint32_t* cigar, const int64_t* cigar_off, strk_stats* stats) {
-    if (stats) memset(stats, 0, sizeof *stats);
-    if (n_pairs < 0) return fail(STRK_E_INVALID, "n_pairs < 0");
-    if (n_pairs == 0) return 0;
-    if (!s1 || !s1_off || !s2 || !s2_off || !out_score || !out_end_ref || !out_n_cigar || !cigar || !cigar_off)
-        return fail(STRK_E_INVALID, "NULL argument");
-    if (open < 0 || ext < 0 || open > 4096 || ext > open) return fail(STRK_E_INVALID, "need 0 <= extend <= open <= 4096");
-    if (gap_pref != 0 && gap_pref != 1) return fail(STRK_E_INVALID, "bad gap_pref");
-    HIP_TRY(hipSetDevice(c->device));
-    size_t trace_budget = (size_t)16 << 30;
-    if (const char* e = getenv("STRKIT_AMD_TRACE_BYTES")) trace_budget = std::max<size_t>((size_t)strtoull(e, nullptr, 10), 1 << 20);
-
-    std::vector<RealignPair> all((size_t)n_pairs);
-    std::vector<size_t> trace_bytes((size_t)n_pairs);
-    for (int p = 0; p < n_pairs; ++p) {
-        const int64_t n1 = s1_off[p + 1] - s1_off[p], n2 = s2_off[p + 1] - s2_off[p], cap = cigar_off[p + 1] - cigar_off[p];
-        if (n1 < 1 || n2 < 1) return fail(STRK_E_INVALID, "pair %d: empty sequence", p);
-        if (n1 > (1 << 20) || n2 > (1 << 24)) return fail(STRK_E_INVALID, "pair %d: sequence too long (%lld x %lld)", p, (long long)n1, (long long)n2);
-        if (cap < 0) return fail(STRK_E_INVALID, "pair %d: negative CIGAR capacity", p);
-        RealignPair& r = all[p];
-        r.s1_off = s1_off[p] - s1_off[0];
-        r.s2_off = s2_off[p] - s2_off[0];
-        r.n1 = (int32_t)n1;
-        r.n2 = (int32_t)n2;
-        r.cl = n1 <= 256 ? 4 : n1 <= 512 ? 8 : n1 <= 1024 ? 16 : 32;
-        r.ntiles = (int32_t)((n1 + 64 * r.cl - 1) / (64 * r.cl));
-        r.pad = r.ntiles * 64 * r.cl - (int32_t)n1;
-        r.cig_cap = (int32_t)std::min<int64_t>(cap, 2 * n1 + 4);
-        r.orig = p;
-        r.reserved = 0;
-        const size_t tb = (size_t)r.ntiles * (size_t)(n2 + 63) * 64 * (size_t)(r.cl / 2);
-        trace_bytes[p] = (tb + 255) & ~(size_t)255;
-        if (trace_bytes[p] > ((size_t)128 << 30)) return fail(STRK_E_NOMEM, "pair %d: trace of %zu bytes", p, trace_bytes[p]);
-    }
-    int rc;
-    const size_t s1_bytes = (size_t)(s1_off[n_pairs] - s1_off[0]), s2_bytes = (size_t)(s2_off[n_pairs] - s2_off[0]);
-    if ((rc = c->rl_s1.ensure(s1_bytes + 16))) return rc;
-    if ((rc = c->rl_s2.ensure(s2_bytes + 16))) return rc;
-    if ((rc = c->rl_queue.ensure(64))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->rl_s1.p, s1 + s1_off[0], s1_bytes, hipMemcpyHostToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(c->rl_s2.p, s2 + s2_off[0], s2_bytes, hipMemcpyHostToDevice, nullptr));
-
-    hipEvent_t ev0 = c->ev[0], ev1 = c->ev[3];
-    for (int p0 = 0; p0 < n_pairs;) {
-        // one chunk: as many pairs (caller order) as fit the trace budget
-        int p1 = p0;
-        size_t tsum = 0, esum = 0, csum = 0;
-        while (p1 < n_pairs && (p1 == p0 || tsum + trace_bytes[p1] <= trace_budget)) {
-            tsum += trace_bytes[p1];
-            if (all[p1].ntiles > 1) esum += (size_t)4 * all[p1].n2;
-            csum += (size_t)all[p1].cig_cap;
-            ++p1;
-        }
-        const int n = p1 - p0;
-        std::vector<RealignPair> chunk(all.begin() + p0, all.begin() + p1);
-        std::stable_sort(chunk.begin(), chunk.end(), [](const RealignPair& x, const RealignPair& y) {   // widest class first, then most work first
-            if (x.cl != y.cl) return x.cl > y.cl;
-            return (int64_t)x.ntiles * (x.n2 + 63) > (int64_t)y.ntiles * (y.n2 + 63);
-        });
-        size_t toff = 0, eoff = 0, coff = 0;
-        for (auto& r : chunk) {
-            r.trace_off = (int64_t)toff;
-            toff += trace_bytes[r.orig];
-            r.edge_off = r.ntiles > 1 ? (int64_t)eoff : -1;
-            if (r.ntiles > 1) eoff += (size_t)4 * r.n2;
-            r.cig_off = (int64_t)coff;
-            coff += (size_t)r.cig_cap;
-            r.orig -= p0;
-        }
-        if ((rc = c->rl_pairs.ensure((size_t)n * sizeof(RealignPair)))) return rc;
-        if ((rc = c->rl_trace.ensure(tsum + 256))) return rc;
-        if ((rc = c->rl_edge.ensure(std::max<size_t>(esum, 1) * 4))) return rc;
-        if ((rc = c->rl_out.ensure((size_t)n * 3 * 4))) return rc;
-        if ((rc = c->rl_cigar.ensure(std::max<size_t>(csum, 1) * 4))) return rc;
-        HIP_TRY(hipMemcpyAsync(c->rl_pairs.p, chunk.data(), (size_t)n * sizeof(RealignPair), hipMemcpyHostToDevice, nullptr));
-        HIP_TRY(hipMemsetAsync(c->rl_queue.p, 0, 64, nullptr));
-        RealignArgs a{};
-        a.pairs = c->rl_pairs.as<RealignPair>();
-        a.n_pairs = n;
-        a.open = open;
-        a.ext = ext;
-        a.gap_pref = gap_pref;
-        a.s1 = c->rl_s1.as<uint8_t>();
-        a.s2 = c->rl_s2.as<uint8_t>();
-        a.trace = c->rl_trace.as<uint8_t>();
-        a.edge = c->rl_edge.as<int32_t>();
-        a.score = c->rl_out.as<int32_t>();
-        a.end2 = a.score + n;
-        a.n_cigar = a.score + 2 * n;
-        a.cigar = c->rl_cigar.as<uint32_t>();
-        a.queue = c->rl_queue.as<int32_t>();
-        a.cells = reinterpret_cast<unsigned long long*>(c->rl_queue.as<char>() + 32);
-        HIP_TRY(hipEventRecord(ev0, nullptr));
-        int32_t* hdbg = nullptr;
-        const bool dbg = getenv("STRKIT_AMD_RL_DEBUG") != nullptr;
-        if (dbg) {   // progress markers per wave of block 0, host-visible (diagnosis of a kernel that does not finish)
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hdbg), 4096, hipHostMallocMapped));
-            memset(hdbg, 0, 4096);
-            a.dbg = hdbg;
-        }
-        for (int first = 0, q = 0; first < n; ++q) {
-            int cnt = 1;
-            while (first + cnt < n && chunk[first + cnt].cl == chunk[first].cl) ++cnt;
-            launch_realign_dp(chunk[first].cl, ext == 0, a, first, cnt, q, c->device);
-            first += cnt;
-        }
-        hipLaunchKernelGGL(k_realign_trace, dim3((n + 63) / 64), dim3(64), 0, nullptr, a);
-        HIP_TRY(hipEventRecord(ev1, nullptr));
-        std::vector<int32_t> o((size_t)n * 3);
-        std::vector<uint32_t> cg(std::max<size_t>(csum, 1));
-        unsigned long long cells = 0;
-        HIP_TRY(hipMemcpyAsync(o.data(), c->rl_out.p, (size_t)n * 3 * 4, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipMemcpyAsync(cg.data(), c->rl_cigar.p, csum * 4, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipMemcpyAsync(&cells, c->rl_queue.as<char>() + 32, 8, hipMemcpyDeviceToHost, nullptr));
-        {   // watchdog: the chunk's cells at a pessimistic 1 GCUPS, plus a minute
-            double work = 0;
-            for (const auto& r : chunk) work += (double)r.ntiles * 64 * r.cl * (r.n2 + 63);
-            const double limit_s = 60.0 + work / 1e9;
-            const auto t0 = std::chrono::steady_clock::now();
-            hipError_t q;
-            while ((q = hipStreamQuery(nullptr)) == hipErrorNotReady) {
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
-                    if (hdbg)
-                        for (int w = 0; w < 4; ++w)
-                            fprintf(stderr, "[strk_realign] wave %d: iters=%d item=%d cl=%d n2=%d t=%d done=%d\n", w, hdbg[w * 8],
-                                    hdbg[w * 8 + 1], hdbg[w * 8 + 2], hdbg[w * 8 + 3], hdbg[w * 8 + 4], hdbg[w * 8 + 5]);
-                    return fail(STRK_E_DEVICE, "realignment kernels did not finish within %.0f s", limit_s);
-                }
-                usleep(50);
-            }
-            if (q != hipSuccess) return fail(STRK_E_DEVICE, "realignment kernels: %s", hipGetErrorString(q));
-        }
-        if (hdbg) (void)hipHostFree(hdbg);
-        HIP_TRY(hipGetLastError());
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-        if (stats) {
-            stats->kernel_ms += ms;
-            stats->dp_kernel_ms += ms;
-            stats->dp_cells += (int64_t)cells;
-            stats->n_dp_launches += 1;
-            stats->exact_bytes += (int64_t)tsum;   // trace bytes written (the kernel's real HBM traffic)
-        }
-        for (const auto& r : chunk) {
-            const int p = r.orig + p0;
-            out_score[p] = o[r.orig];
-            out_end_ref[p] = o[(size_t)n + r.orig];
-            const int32_t nc = o[(size_t)2 * n + r.orig];
-            if (nc < 0) return fail(STRK_E_INVALID, "pair %d: CIGAR capacity %d too small", p, r.cig_cap);
-            out_n_cigar[p] = nc;
-            memcpy(cigar + cigar_off[p], cg.data() + r.cig_off, (size_t)nc * 4);
-        }
-        p0 = p1;
-    }
-    return 0;
-}
+#include "strk_host_realign.inc"
 
 }  // namespace
 
