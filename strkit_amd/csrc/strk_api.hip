@@ -40,7 +40,11 @@ thread_local std::string g_err;
 // device with others takes half the CU slots, so that the tail of one call and the head of the next co-run
 std::atomic<int> g_calls_in_flight{0};
 
-// consecutive default-window calls of this process without a window miss (negative: the wide window is enforced)
+// Default candidate window of this process (one sample, whatever context a call runs on): level into kWindowLevels,
+// and the number of consecutive default-window calls without a window miss since the level last changed.
+// Misses cost extra rounds on the host: a call with more than a handful (> 0.4 % of its loci) moves a level up at
+// once; eight (from the two widest levels: sixty-four) calls in a row without any move a level down.
+std::atomic<int> g_win_level{1};
 std::atomic<int> g_win_quiet{0};
 
 int fail(int code, const char* fmt, ...) {
@@ -122,7 +126,7 @@ namespace {
 using namespace strk;
 
 constexpr int kDefaultWindow = 8;
-constexpr int kQuietWindow = 6;    // default window of a context whose recent calls never left their windows
+constexpr int kWindowLevels[4] = {6, 8, 11, 15};   // default half-widths of the candidate window, see g_win_level
 // Scratch pool (int32 units): kLongWaves slots of kLongSlotInts for k_dp_long (one per resident wave; a slot
 // holds the backward row of all column tiles + two boundary columns: windows up to ~16 kb), then 16 Mi
 // ints of H rows for the generic kernel.  448 MiB of the 288 GB, allocated once per context.
@@ -265,12 +269,12 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     int rc;
     if ((rc = check_params(params, &p))) return rc;
     if (!b || b->n_reads < 0 || b->n_loci < 0) return fail(STRK_E_INVALID, "bad batch");
-    // default window: 8 sizes either side of the estimate; 6 once eight calls in a row (of this process: one sample,
-    // whatever context they ran on) stayed inside their windows.  A miss costs an extra round on the host, so a single
-    // one brings the wide window back for 64 calls.
+    // default window: 8 sizes either side of the estimate to begin with, then what the sample needs (g_win_level)
     c->p_window_auto = params->window <= 0;
-    if (c->p_window_auto && g_win_quiet.load(std::memory_order_relaxed) >= 8 && p.local_search_range + p.step_size + 2 <= kQuietWindow)
-        p.window = kQuietWindow;
+    if (c->p_window_auto) {
+        const int w = kWindowLevels[std::min(3, std::max(0, g_win_level.load(std::memory_order_relaxed)))];
+        p.window = std::max(w, std::min(kWindowLevels[3], p.local_search_range + p.step_size + 2));
+    }
     c->p_batch = *b;
     c->p_params = p;
     c->p_stream = st;
@@ -346,9 +350,23 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
     fprintf(stderr, "[phase ticks/64] header %d stage %d tables %d bwd %d fwd %d epilogue %d\n", c->h_counters[40], c->h_counters[41],
             c->h_counters[42], c->h_counters[43], c->h_counters[44], c->h_counters[45]);
 #endif
-    if (c->p_window_auto) {
-        if (c->h_counters[kCntMiss] > 0) g_win_quiet.store(-64, std::memory_order_relaxed);
-        else if (g_win_quiet.load(std::memory_order_relaxed) < (1 << 20)) g_win_quiet.fetch_add(1, std::memory_order_relaxed);
+    int n_band_reads = 0;
+    for (int k = 0; k < kNumBandClasses; ++k) n_band_reads += c->h_counters[kCntClass0 + kBandClass0 + k];
+    // (a call whose band certificates mostly failed reports those reads as misses too: not a window problem)
+    const bool band_unhealthy = c->p_args.band_mode && n_band_reads >= 64 && 2 * c->h_counters[kCntBandFallback] > n_band_reads;
+    if (c->p_window_auto && !band_unhealthy) {
+        const int level = g_win_level.load(std::memory_order_relaxed);
+        // a handful of misses costs less (one short extra round) than a wider window for every read does
+        const int n_miss = c->h_counters[kCntMiss];
+        if (n_miss > std::max(2, b->n_loci / 250)) {
+            if (level < 3) g_win_level.store(level + 1, std::memory_order_relaxed);
+            g_win_quiet.store(level == 0 ? -56 : 0, std::memory_order_relaxed);   // a failed narrow window is not retried soon
+        } else if (n_miss > 0) {
+            g_win_quiet.store(0, std::memory_order_relaxed);
+        } else if (g_win_quiet.fetch_add(1, std::memory_order_relaxed) + 1 >= (level >= 2 ? 64 : 8) && level > 0) {
+            g_win_level.store(level - 1, std::memory_order_relaxed);
+            g_win_quiet.store(0, std::memory_order_relaxed);
+        }
     }
     {   // queue lengths of this call, for the grids of the next one (enqueue_scoring)
         int exact_chunks = 0, wide_chunks = 0;
