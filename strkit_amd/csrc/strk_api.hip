@@ -106,6 +106,7 @@ struct strk_ctx {
     size_t scratch_ints = 0;
     int band_cooldown = 0;   // > 0: the band kernel is switched off for that many calls (too many certificates failed)
     int band_penalty = 32;   // length of the next cool-down (doubles while retries keep failing)
+    bool band_probation = true;   // the band has not proved itself on this context's data yet: only a sample of the reads takes it
     bool p_window_auto = false;
     // work-queue lengths of the previous finished call (wave chunks), used to size the persistent grids of the
     // kernels that usually have little or nothing to do: an idle block still claims its 70-80 KB of LDS on a CU
@@ -126,6 +127,7 @@ namespace {
 using namespace strk;
 
 constexpr int kDefaultWindow = 8;
+constexpr int kBandProbationReads = 2048;
 constexpr int kWindowLevels[4] = {6, 8, 11, 15};   // default half-widths of the candidate window, see g_win_level
 // Scratch pool (int32 units): kLongWaves slots of kLongSlotInts for k_dp_long (one per resident wave; a slot
 // holds the backward row of all column tiles + two boundary columns: windows up to ~16 kb), then 16 Mi
@@ -206,6 +208,7 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
         a.rhash = sp->no_dedupe ? nullptr : c->rhash.as<unsigned long long>();
         a.exact = c->exact.as<uint8_t>();
         a.band_mode = (!sp->no_band && c->band_cooldown == 0) ? 1 : 0;
+        a.band_limit = c->band_probation ? kBandProbationReads : INT32_MAX;
     }
     return a;
 }
@@ -385,19 +388,22 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         c->hist_wide_chunks = wide_chunks;
         c->hist_long = c->h_counters[kCntClass0 + kLongClass];
     }
-    {   // adaptive: noisy reads mostly fail the certificate and pay for both passes
+    {   // adaptive: noisy reads mostly fail the certificate and pay for both passes.  A context starts on probation
+        // (the band sees the first kBandProbationReads reads of a call only, so a failure is cheap); a call with fewer
+        // than half of its band reads falling back ends it, one with more switches the band off for a while and for
+        // twice as long every time a retry (again on probation) fails.
         int nb = 0;
         for (int k = 0; k < kNumBandClasses; ++k) nb += c->h_counters[kCntClass0 + kBandClass0 + k];
         if (c->band_cooldown > 0) {
             --c->band_cooldown;
         } else if (nb >= 64) {
-            // more than half of the band reads fell back: switch the band off for a while, and for twice as long
-            // every time a retry fails again (a failed retry costs a full extra pass plus host rounds)
             if (2 * c->h_counters[kCntBandFallback] > nb) {
                 c->band_cooldown = c->band_penalty;
                 c->band_penalty = std::min(c->band_penalty * 2, 1 << 14);
+                c->band_probation = true;
             } else {
                 c->band_penalty = 32;
+                c->band_probation = false;
             }
         }
     }

@@ -95,6 +95,7 @@ struct KArgs {
     int32_t table_stride; // entries per read (plan kernel)
     int32_t max_iters, lsr, step, tie_last;  // search parameters (speculative search in k_dp_all)
     int32_t band_mode;    // 1: eligible reads go through k_dp_band first (strk_search.h, "Banded scoring")
+    int32_t band_limit;   // only reads with index < band_limit are eligible (a context on probation tries the band on a sample)
     uint8_t* exact;       // [n_reads] 1: the read's table holds exact scores, 0: band lower bounds
     int32_t ref_mode;     // 1: reference-side scoring (repeats.py:23-43): candidate = fl + motif*i only, the
                           //    table holds (score, end_query) pairs, end_flags must be STRK_DB_END_FREE
@@ -245,7 +246,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     unsigned long long cells = 0;
     const unsigned long long ndb = (unsigned long long)nfl + ntr + nfr;
     int band_list = -1;   // >= 0: the read goes to the band kernel first
-    if (a.band_mode && mode == 0 && n > 0 && n <= kTableMax && !force_generic) {
+    if (a.band_mode && mode == 0 && n > 0 && n <= kTableMax && !force_generic && r < a.band_limit) {
         const BandGeo geo = band_geometry(nfl, ntr, nfr, m, lo, n);
         if (geo.ok) band_list = kBandClass0 + geo.cls;
     }
