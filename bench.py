@@ -88,6 +88,7 @@ def main() -> None:
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--no-dedupe", action="store_true", help="score identical reads of a locus separately")
     ap.add_argument("--no-band", action="store_true", help="exact kernels only (no banded first pass)")
+    ap.add_argument("--gather-every", type=int, default=8, help="steps per result all-gather when several ranks run")
     ap.add_argument("--pipeline", type=int, default=4, help="batched calls in flight (contexts/streams)")
     ap.add_argument("--cpu-sample-loci", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,14 +138,27 @@ def main() -> None:
     ctxs = [_lib.Context(local_rank) for _ in range(D)]
     streams = [torch.cuda.Stream(dev) for _ in range(D)]
     outs = [torch.zeros((4, b.n_reads), dtype=torch.int32, device=dev) for _ in range(D)]  # cn | score | n_iters | start
-    gathered = [torch.zeros((world * 4, b.n_reads), dtype=torch.int32, device=dev) for _ in range(D)] if use_dist else None
+    # Results of every step are collected on every rank (RCCL all-gather over xGMI), G steps per collective: the
+    # reference merges its workers' results once per contig (call_sample.py:195-197,420), not once per locus block.
+    # The kernels write straight into the staging buffer of their round (two buffers: steps of the next round are in
+    # flight while a round is being gathered), so collecting costs no extra copy.
+    G = max(D, a.gather_every)
+    stage = torch.zeros((2, G * 4, b.n_reads), dtype=torch.int32, device=dev) if use_dist else None
+    gathered = torch.zeros((world * G * 4, b.n_reads), dtype=torch.int32, device=dev) if use_dist else None
+
+    def out_of(i):
+        if not use_dist:
+            return outs[i % D]
+        j = i % G
+        return stage[(i // G) % 2, 4 * j:4 * j + 4]
+
     acc = dict(dp_ms=0.0, band_ms=0.0, all_ms=0.0, misses=0, fallback=0, dedup=0, band=0, band_fb=0, n=0)
 
     def submit(i):
         k = i % D
-        if use_dist:
-            streams[k].wait_stream(torch.cuda.current_stream(dev))  # the previous gather of this slot has read outs[k]
-        o = outs[k]
+        if use_dist and i % G < D:   # first use of this stream in a round: the collective that last read the round's buffer is done
+            streams[k].wait_stream(torch.cuda.current_stream(dev))
+        o = out_of(i)
         _lib.check(L.strk_submit_loci_device(ctxs[k].handle, C.byref(sb), C.byref(p), o[0].data_ptr(), o[1].data_ptr(),
                                              o[2].data_ptr(), o[3].data_ptr(), C.c_void_p(streams[k].cuda_stream)))
 
@@ -156,8 +170,8 @@ def main() -> None:
             acc["band"] += st.n_band_reads; acc["band_fb"] += st.n_band_fallback
             acc["misses"] += st.n_miss_reads; acc["fallback"] += st.n_fallback; acc["dedup"] += st.n_dedup_reads
             acc["n"] += 1
-        if use_dist:  # collect per-read results of every shard (RCCL all-gather over xGMI)
-            dist.all_gather_into_tensor(gathered[k], outs[k])
+        if use_dist and (i + 1) % G == 0:  # a round is complete: collect it from every shard
+            dist.all_gather_into_tensor(gathered, stage[(i // G) % 2])
 
     def run(n_steps, timed):
         for i in range(min(D, n_steps)):
@@ -173,14 +187,20 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def flush(n_steps):
+        if use_dist and n_steps % G:   # the last, partial round (the collective always moves the full buffer)
+            dist.all_gather_into_tensor(gathered, stage[((n_steps - 1) // G) % 2])
+
     run(a.warmup, False)
+    flush(a.warmup)
     fence()
     t0 = time.perf_counter()
     run(a.steps, True)
+    flush(a.steps)
     fence()
     elapsed = time.perf_counter() - t0
     dp_ms, all_ms, misses, fallback = acc["dp_ms"], acc["all_ms"], acc["misses"], acc["fallback"]
-    out = outs[(a.steps - 1) % D]
+    out = out_of(a.steps - 1).clone()
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -239,7 +259,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": WORKLOAD if a.config == 2 and a.loci is None else f"cfg{a.config}, {b.n_loci} loci per GPU",
                        "loci_per_gpu": b.n_loci, "reads_per_gpu": b.n_reads, "window": int(p.window) or 8,
-                       "parallelism": f"loci-sharded x{a.gpus}" + (" + all_gather" if use_dist else ""),
+                       "parallelism": f"loci-sharded x{a.gpus}" + (f" + all_gather every {G} steps" if use_dist else ""),
                        "calls_in_flight": D},
             "loci_per_s": n_loci_all * a.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": alg_bytes / dp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -262,7 +282,8 @@ def main() -> None:
         }
         print(json.dumps(line), flush=True)
     if use_dist:
-        if rank == 0 and not torch.equal(gathered[(a.steps - 1) % D][:4], out):
+        j = (a.steps - 1) % G   # rank 0's block of the last collective, slot of the last step
+        if rank == 0 and not torch.equal(gathered[4 * j:4 * j + 4], out):
             sys.exit("all_gather self-check failed")
         dist.destroy_process_group()
     for c in ctxs:
