@@ -109,7 +109,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     if (FLY) { wordNext = x.tbl[next_sym()]; symNext = next_sym(); }
     else { wordNext = x.tbl[pa[0]]; symNext = pa[1]; }
     unsigned nbNext = x.selb[col_addr(jb + 16)];       // class byte entering at the next row
-#define STRK_BAND_STEP(SRC, DST, TT)                                                               \
+#define STRK_BAND_STEP(SRC, DST, TT, EDGE)                                                         \
     {                                                                                              \
         const uint2 word = wordNext;                                                               \
         wordNext = x.tbl[symNext];                                                                 \
@@ -117,11 +117,11 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         const unsigned nb = nbNext;                                                                \
         nbNext = x.selb[col_addr(jb + 17)];                                                        \
         /* lane 0 works on row TT+1; left of the band lies the left boundary while j-1 <= 0 */      \
-        const int keepL = ((TT) + dlo_ <= 0 && leftFree) ? g * ((TT) + 1) : 0;                      \
+        const int keepL = ((EDGE) && (TT) + dlo_ <= 0 && leftFree) ? g * ((TT) + 1) : 0;            \
         const int leftEdge = from_left<G>(keepL, houtL, x.first);                                  \
         /* the last lane works on row TT-G+2; above row 1 lies the row-0 pattern, else -inf */      \
         const int rl = (TT) - G + 2;                                                               \
-        const int keepU = rl <= 1 ? g0(rl + dhi_) : 0;                                             \
+        const int keepU = ((EDGE) && rl <= 1) ? g0(rl + dhi_) : 0;                                 \
         const unsigned w0 = __builtin_amdgcn_perm(word.y, word.x, sel[0]);                         \
         const unsigned w1 = __builtin_amdgcn_perm(word.y, word.x, sel[1]);                         \
         const unsigned w2 = __builtin_amdgcn_perm(word.y, word.x, sel[2]);                         \
@@ -161,9 +161,17 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         }                                                                                          \
         ++jb;                                                                                      \
     }
-    for (int t = 0; t < T; t += 2) {
-        STRK_BAND_STEP(Ha, Hb, t)
-        STRK_BAND_STEP(Hb, Ha, t + 1)
+    // The band touches the left boundary column while t <= -dlo and the row-0 pattern while t <= G - 1: after that
+    // (for every group of the wave) both edge values are the constant 0 and the steps need not compute them.
+    const int tEdge = min(T, (wave_max_over_groups(max(1 - dlo_, G)) + 1) & ~1);
+    int t = 0;
+    for (; t < tEdge; t += 2) {
+        STRK_BAND_STEP(Ha, Hb, t, true)
+        STRK_BAND_STEP(Hb, Ha, t + 1, true)
+    }
+    for (; t < T; t += 2) {
+        STRK_BAND_STEP(Ha, Hb, t, false)
+        STRK_BAND_STEP(Hb, Ha, t + 1, false)
     }
 #undef STRK_BAND_STEP
 }
@@ -426,7 +434,8 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
         else break;
     }
 }
-__global__ void __launch_bounds__(256) k_dp_band(KArgs a) { band_kernel_body<0>(a); }
-__global__ void __launch_bounds__(256) k_dp_band_wide(KArgs a) { band_kernel_body<1>(a); }
+// two blocks (eight waves) per CU: the register allocation must stay within 256 VGPRs
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_dp_band(KArgs a) { band_kernel_body<0>(a); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_dp_band_wide(KArgs a) { band_kernel_body<1>(a); }
 
 }  // namespace strk
