@@ -94,7 +94,7 @@ struct DevBuf {
 struct strk_ctx {
     int device = 0;
     // workspace
-    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, counters, scratch, state_i32, state_f64, spec, rhash, rep, exact;
+    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, band_recs, counters, scratch, state_i32, state_f64, spec, rhash, rep, exact;
     DevBuf win_lo2, win_n2, tab_off2, table2, items;
     // staging for the host-buffer entry points
     DevBuf in_seqs, in_seq_off, in_nfl, in_ntr, in_nfr, in_est, in_read_off, in_motifs, in_motif_off;
@@ -162,6 +162,7 @@ int ensure_workspace(strk_ctx* c, int n_reads, int n_loci, size_t table_ints, si
     if ((rc = c->tab_off.ensure(nr * 8))) return rc;
     if ((rc = c->table.ensure(std::max<size_t>(table_ints, 1) * 4))) return rc;
     if ((rc = c->cls_list.ensure((size_t)kNumLists * std::max<size_t>(n_items, 1) * 2 * 4))) return rc;
+    if ((rc = c->band_recs.ensure((size_t)kNumBandClasses * std::max<size_t>(n_items, 1) * 3 * sizeof(int4)))) return rc;
     if ((rc = c->counters.ensure(kCountersBytes))) return rc;
     if ((rc = c->state_i32.ensure(nl * 3 * 4))) return rc;
     if ((rc = c->state_f64.ensure(nl * 8))) return rc;
@@ -189,6 +190,7 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
     a.tab_off = c->tab_off.as<int64_t>();
     a.table = c->table.as<int32_t>();
     a.cls_list = c->cls_list.as<int32_t>();
+    a.band_recs = c->band_recs.as<int4>();
     a.counters = c->counters.as<int32_t>();
     a.cells = reinterpret_cast<unsigned long long*>(c->counters.as<char>() + kCellsOff);
     a.scratch_used = a.cells + 1;
@@ -350,8 +352,8 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
     }
 #ifdef STRK_PHASE_TIMING
-    fprintf(stderr, "[phase ticks/64] header %d stage %d tables %d bwd %d fwd %d epilogue %d\n", c->h_counters[40], c->h_counters[41],
-            c->h_counters[42], c->h_counters[43], c->h_counters[44], c->h_counters[45]);
+    fprintf(stderr, "[phase ticks/64] header %d stage %d (of which window bytes %d) tables %d bwd %d fwd %d epilogue %d\n", c->h_counters[40],
+            c->h_counters[41] + c->h_counters[46], c->h_counters[46], c->h_counters[42], c->h_counters[43], c->h_counters[44], c->h_counters[45]);
 #endif
     int n_band_reads = 0;
     for (int k = 0; k < kNumBandClasses; ++k) n_band_reads += c->h_counters[kCntClass0 + kBandClass0 + k];
@@ -576,7 +578,7 @@ int strk_init(int device, strk_ctx** out) {
 void strk_destroy(strk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf* bufs[] = {&c->read_locus, &c->win_lo, &c->win_n, &c->tab_off, &c->table, &c->cls_list, &c->counters,
+    DevBuf* bufs[] = {&c->read_locus, &c->win_lo, &c->win_n, &c->tab_off, &c->table, &c->cls_list, &c->band_recs, &c->counters,
                       &c->scratch, &c->state_i32, &c->state_f64, &c->spec, &c->rhash, &c->rep, &c->exact, &c->win_lo2, &c->win_n2, &c->tab_off2, &c->table2,
                       &c->items, &c->in_seqs, &c->in_seq_off, &c->in_nfl, &c->in_ntr, &c->in_nfr, &c->in_est,
                       &c->in_read_off, &c->in_motifs, &c->in_motif_off, &c->out_cn, &c->out_score, &c->out_n,

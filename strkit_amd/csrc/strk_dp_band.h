@@ -191,11 +191,11 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
 
 // Processes 64/G items of band class BC (G = 8 << BC lanes per read), one per group.
 template <int BC>
-__device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw, const uint8_t* s_enc, const int8_t* s_mat) {
+__device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int4 q1, int4 q2, uint8_t* Lw, const uint8_t* s_enc,
+                                          const int8_t* s_mat) {
     constexpr int g = kGap, G = 8 << BC;
     constexpr bool FLY = band_class_fly(BC);
     constexpr BandLayout lay(BC);
-    const int cls = kBandClass0 + BC;
     const int lane = threadIdx.x & 63;
 #ifdef STRK_PHASE_TIMING
     unsigned long long tphase = __builtin_readcyclecounter();
@@ -214,24 +214,15 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
     short* const b0col = reinterpret_cast<short*>(Lg + lay.off_b0);
     uint8_t* const motifL = FLY ? cp + 256 : Lg + lay.off_b0;   // non-FLY: the motif sits in b0col until that is initialised
 
-    const int count = min(a.counters[kCntClass0 + cls], a.list_stride);
-    const int32_t* list = a.cls_list + (size_t)cls * a.list_stride * 2;
-    const int it = base + grp;
-    bool act = it < count;
+    // the item's record was fetched by the caller while the previous chunk was being processed
     int r = 0, nfl = 1, ntr = 0, nfr = 1, m = 1, lo = 0, n = 0;
     long long soff = 0;
     const uint8_t* motif = a.motifs;
     if (act) {
-        const int2 item = reinterpret_cast<const int2*>(list)[it];   // (read, locus): two levels of dependent loads, not three
-        r = item.x;
-        const int l = item.y;
-        const int mo0 = a.motif_off[l], mo1 = a.motif_off[l + 1];
-        nfl = a.nfl[r]; ntr = a.ntr[r]; nfr = a.nfr[r];
-        soff = a.seq_off[r];
-        lo = a.win_lo[r];
-        n = a.win_n[r];
-        motif += mo0;
-        m = mo1 - mo0;
+        r = q0.x; nfl = q0.z; ntr = q0.w;
+        nfr = q1.x; m = q1.y; lo = q1.z; n = q1.w;
+        soff = (long long)(((unsigned long long)(unsigned)q2.y << 32) | (unsigned)q2.x);
+        motif += q2.z;
     }
     const int ndb = nfl + ntr + nfr;
     const BandGeo geo = band_geometry(nfl, ntr, nfr, m, lo, max(n, 1));
@@ -282,6 +273,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, int base, uint8_t* Lw,
                 if (d < ND) selw[d] = out;
             }
         }
+        STRK_PHASE(6);
         if (mask) atomicOr(reinterpret_cast<unsigned*>(&misc[0]), mask);
         for (int k = lig; k < m; k += G) motifL[k] = act ? s_enc[motif[k]] : (uint8_t)kNullSym;
     }
@@ -424,14 +416,53 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
     uint8_t* const Lw = lds + (threadIdx.x >> 6) * kBandWaveLds;
     constexpr int perA = 64 / (8 << CA), perB = 64 / (8 << CB);   // reads per wave
     const int chA = (nA + perA - 1) / perA, chB = (nB + perB - 1) / perB;
-    for (;;) {
-        __builtin_amdgcn_wave_barrier();   // the wave enters every iteration whole (see k_realign_dp)
+    const int lane = threadIdx.x & 63;
+    auto pop = [&]() {
         int c = 0;
-        if ((threadIdx.x & 63) == 0) c = atomicAdd(&a.counters[kCntNextBand + SET], 1);
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (c < chA) band_wave<CA>(a, c * perA, Lw, s_enc, s_mat);
-        else if (c - chA < chB) band_wave<CB>(a, (c - chA) * perB, Lw, s_enc, s_mat);
-        else break;
+        if (lane == 0) c = atomicAdd(&a.counters[kCntNextBand + SET], 1);
+        return __builtin_amdgcn_readfirstlane(c);
+    };
+    // record of this lane's item in chunk c (chunks of the wider class come first)
+    auto fetch = [&](int c, bool& act, int4& q0, int4& q1, int4& q2) -> int {
+        int cls = CA, it = 0, cnt = 0;
+        if (c < chA) { cls = CA; it = c * perA + lane / (8 << CA); cnt = nA; }
+        else if (c - chA < chB) { cls = CB; it = (c - chA) * perB + lane / (8 << CB); cnt = nB; }
+        act = it < cnt;
+        if (act) {
+            const int4* rec = a.band_recs + ((size_t)cls * a.list_stride + it) * 3;
+            q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
+        }
+        return 8 << cls;   // lanes per item of that chunk
+    };
+    // Touch the window bytes of an item one chunk early (one byte per 64-byte line, a line per lane of the group), so
+    // that the staging loop of its chunk finds them in cache.  The loaded byte itself is never used.
+    auto touch = [&](bool act_, const int4& q0_, const int4& q1_, const int4& q2_, int G_) -> unsigned {
+        unsigned sink = 0;
+        if (act_) {
+            const long long so = (long long)(((unsigned long long)(unsigned)q2_.y << 32) | (unsigned)q2_.x);
+            const int ndb_ = q0_.z + q0_.w + q1_.x;
+            const uint8_t* pp = a.seqs + so + min((lane & (G_ - 1)) * 64, max(ndb_ - 1, 0));
+            asm volatile("global_load_ubyte %0, %1, off" : "=v"(sink) : "v"(pp) : "memory");
+        }
+        return sink;
+    };
+    int c = pop();
+    bool act = false;
+    int4 q0 = make_int4(0, 0, 0, 0), q1 = q0, q2 = q0;
+    (void)fetch(c, act, q0, q1, q2);
+    while (c < chA + chB) {
+        __builtin_amdgcn_wave_barrier();   // the wave enters every iteration whole (see k_realign_dp)
+        // take the next chunk now and start loading its records: they arrive while this chunk is being processed
+        const int cn = pop();
+        bool act_n = false;
+        int4 n0 = make_int4(0, 0, 0, 0), n1 = n0, n2 = n0;
+        const int g_n = fetch(cn, act_n, n0, n1, n2);
+        const unsigned sink = touch(act_n, n0, n1, n2, g_n);
+        if (c < chA) band_wave<CA>(a, act, q0, q1, q2, Lw, s_enc, s_mat);
+        else band_wave<CB>(a, act, q0, q1, q2, Lw, s_enc, s_mat);
+        // the touch load's destination register stays reserved until the load has certainly landed
+        asm volatile("s_waitcnt vmcnt(0)" : : "v"(sink) : "memory");
+        c = cn; act = act_n; q0 = n0; q1 = n1; q2 = n2;
     }
 }
 // two blocks (eight waves) per CU: the register allocation must stay within 256 VGPRs

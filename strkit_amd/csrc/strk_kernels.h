@@ -77,6 +77,8 @@ struct KArgs {
     int64_t* tab_off;     // [n_reads]
     int32_t* table;       // score table
     int32_t* cls_list;    // [kNumLists * list_stride * 2]  (read, chunk start) pairs
+    int4* band_recs;      // [kNumBandClasses * list_stride * 3]  everything a band item needs, written by k_plan:
+                          //   (read, locus, nfl, ntr) (nfr, m, lo, n) (seq_off lo, seq_off hi, motif_off, 0)
     int32_t* counters;    // see Counter enum
     unsigned long long* cells;  // DP cells executed; cells[2] / cells[3]: algorithmic bytes (|window| + 16 per read) of the
                                 // items routed to the band kernel / to the exact kernels by k_plan
@@ -286,6 +288,13 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
         if (idx < a.list_stride) {
             a.cls_list[(size_t)c * a.list_stride * 2 + 2 * idx] = r;
             a.cls_list[(size_t)c * a.list_stride * 2 + 2 * idx + 1] = band_list >= 0 ? l : k0;   // band items: the locus (k0 is 0)
+            if (band_list >= 0) {   // the band kernel fetches an item with one level of loads (and one chunk ahead)
+                int4* rec = a.band_recs + ((size_t)(band_list - kBandClass0) * a.list_stride + idx) * 3;
+                const long long so = a.seq_off[r];
+                rec[0] = make_int4(r, l, nfl, ntr);
+                rec[1] = make_int4(nfr, m, lo, n);
+                rec[2] = make_int4((int)(so & 0xffffffffll), (int)(so >> 32), a.motif_off[l], 0);
+            }
         } else {
             atomicOr(&a.counters[kCntError], kErrScratch);
         }
