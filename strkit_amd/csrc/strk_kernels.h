@@ -232,6 +232,9 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
                     if (a.rhash[q] == h && same_read(a, r, q)) { rep = q; break; }  // first occurrence
             }
             a.rep[r] = rep;
+            // no speculative result yet: the kernels that score a read AND search it overwrite this, a read that ends in
+            // the generic kernel (scores only) keeps it and is searched by k_replay on its table
+            if (a.spec) a.spec[r] = make_int4(0, 0, 0, kSpecMiss);
             a.win_lo[r] = lo;
             a.win_n[r] = n;
             a.tab_off[r] = (int64_t)rep * a.table_stride;

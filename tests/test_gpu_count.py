@@ -146,3 +146,17 @@ def test_band_kernel_certifies_hifi_and_falls_back_on_noise(gpu_ctx):
     for window in (0, 4):
         gotl, stl = _run(bl, gpu_ctx, window=window)
         _compare(bl, gotl, expl)
+
+
+def test_reads_with_more_than_eight_symbol_classes_are_searched_on_the_generic_table(gpu_ctx):
+    """IUPAC motif + wildcarded read: nine distinct symbols exceed a v_perm word, the read is scored by the generic
+    kernel, which does not search; k_replay must search its table even when the start equals the estimate (no
+    feedback).  Found by tests/test_gpu_fuzz.py (seed 12695296)."""
+    fl = "GAAAXCNNACAAATNNANXTXTGGCGTXNNTNGAAXCCAGTXCTGXCTXAGNAXGATGTTTXCCATCNTNGAXNXAANNXACGXNX"
+    fr = "CATANCTAXAXANTATTCXNAGCGTXCGCGCATNNGNAXTACGCTCGTGTNGTGAXATX"
+    b = LocusBatch.from_reads([("VKB", [(fl, "VKB" * 23, fr), (fl, "VKB" * 21 + "VK", fr)]), ("CAG", [("ACGTTGCA" * 5, "CAG" * 9, "TTGACCA" * 6)])])
+    for feedback in (False, True):
+        for band in (False, True):
+            got, st = _run(b, gpu_ctx, max_iters=7, lsr=1, feedback=feedback, band=band)
+            assert st["n_fallback"] == 2
+            _compare(b, got, oracle_count(b, 7, 1, 1, 0, 15, feedback))
