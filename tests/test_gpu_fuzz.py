@@ -71,7 +71,9 @@ def _one_realign_case(rng):
 
 
 def test_random_batches_and_options_match_the_oracle(gpu_ctx):
-    seed = int(os.environ.get("STRK_FUZZ_SEED", str(int(time.time()) & 0xFFFFFF)))
+    # the routine run is reproducible; a soak run (STRK_FUZZ_SECONDS set) draws a fresh seed unless one is given
+    default_seed = str(int(time.time()) & 0xFFFFFF) if "STRK_FUZZ_SECONDS" in os.environ else "20261004"
+    seed = int(os.environ.get("STRK_FUZZ_SEED", default_seed))
     rng = np.random.default_rng(seed)
     t0, cases, reads, pairs = time.time(), 0, 0, 0
     try:
