@@ -70,19 +70,50 @@ def _one_realign_case(rng):
     return n
 
 
+def _one_ref_case(rng):
+    from strkit_amd.repeat_count_params import get_reference_rc_params
+    from strkit_amd.repeats import get_ref_repeat_counts
+    jobs = []
+    for _ in range(int(rng.integers(1, 16))):
+        alpha = [ALPHA_ACGT, ALPHA_ACGT, "ACGTN"][int(rng.integers(3))]
+        m = int(rng.integers(1, 10))
+        motif = rand_seq(rng, m)
+        cn = int(rng.integers(0, int(rng.choice([12, 60, 400]))))
+        fl, fr = rand_seq(rng, int(rng.integers(6, 90)), alpha), rand_seq(rng, int(rng.integers(6, 90)), alpha)
+        tr = motif * cn
+        if rng.random() < 0.4:
+            fl = fl[:max(1, len(fl) - m)] + motif          # the tract spills into a flank
+        if rng.random() < 0.4:
+            fr = motif + fr
+        if tr and rng.random() < 0.4:
+            cut = int(rng.integers(len(tr)))
+            tr = tr[:cut] + rand_seq(rng, int(rng.integers(1, 4))) + tr[cut:]
+        est = max(0, round(len(tr) / m) + int(rng.integers(-3, 4)))
+        jobs.append((est, tr, fl, fr, motif, len(tr), get_reference_rc_params("repalign", est, int(rng.choice([100, 20])))))
+    anchor, respect = int(rng.choice([5, 0, 12])), bool(rng.integers(2))
+    got = get_ref_repeat_counts(jobs, anchor, respect)
+    for (est, tr, fl, fr, motif, ref_size, rc), g in zip(jobs, got):
+        exp = oracle.ref_repeat_count(est, tr, fl, fr, motif, ref_size, anchor, rc.max_iters, rc.initial_local_search_range,
+                                      rc.initial_step_size, respect)
+        assert g == exp, (est, len(tr), len(fl), len(fr), motif, anchor, respect, rc, g[:4], exp[:4])
+    return len(jobs)
+
+
 def test_random_batches_and_options_match_the_oracle(gpu_ctx):
     # the routine run is reproducible; a soak run (STRK_FUZZ_SECONDS set) draws a fresh seed unless one is given
     default_seed = str(int(time.time()) & 0xFFFFFF) if "STRK_FUZZ_SECONDS" in os.environ else "20261004"
     seed = int(os.environ.get("STRK_FUZZ_SEED", default_seed))
     rng = np.random.default_rng(seed)
-    t0, cases, reads, pairs = time.time(), 0, 0, 0
+    t0, cases, reads, pairs, loci = time.time(), 0, 0, 0, 0
     try:
         while time.time() - t0 < SECONDS or cases < 12:
             if cases % 4 == 3:
                 pairs += _one_realign_case(rng)
+            elif cases % 8 == 6:
+                loci += _one_ref_case(rng)
             else:
                 reads += _one_count_case(rng, gpu_ctx)
             cases += 1
     except AssertionError as e:
         raise AssertionError(f"fuzz seed {seed}, case {cases}: {e}") from e
-    print(f"\n[fuzz seed {seed}] {cases} cases, {reads} reads, {pairs} realignments in {time.time() - t0:.1f} s")
+    print(f"\n[fuzz seed {seed}] {cases} cases, {reads} reads, {pairs} realignments, {loci} reference-side loci in {time.time() - t0:.1f} s")
