@@ -197,3 +197,41 @@ def test_realign_cigar_becomes_a_read_alignment():
     mk = lambda runs: np.array([(n << 4) | enc[o] for n, o in runs], np.uint32)  # noqa: E731
     got = realign_cigar_to_read_alignment(mk([(500, "D"), (70, "="), (12, "D"), (30, "="), (2, "I"), (40, "=")]))
     assert got.tolist() == mk([(500, "S"), (70, "="), (12, "I"), (30, "="), (2, "D"), (40, "=")]).tolist()
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (101, dict(read_len=900, sub=0.0, indel=0.0)),
+    (102, dict(read_len=2500, sub=0.03, indel=0.05, low_qual=0.05)),
+    (103, dict(read_len=1200, sub=0.01, indel=0.01, soft_clip_frac=0.8, expansion=25, motif_len=(1, 3))),
+    (104, dict(read_len=1500, sub=0.02, indel=0.02, low_qual=0.3, motif_len=(5, 12), cn_range=(3, 12))),
+])
+def test_native_extraction_on_varied_datasets(tmp_path, seed, kw):
+    """Whole-catalog comparison of strk_extract_reads with extract.py under different error, clipping and quality
+    regimes, with shifted boundaries (as the reference-side offsets produce them) and two flank sizes."""
+    from strkit_amd.frontend import NativeBam, extract_reads, get_read_coords_from_cigar
+    t = make_dataset(str(tmp_path), n_loci=10, reads_per_locus=8, seed=seed, **kw)
+    nb, pb = NativeBam(t["paths"]["bam"]), read_bam(t["paths"]["bam"])
+    (block,) = load_loci(t["paths"]["loci"])
+    rng = np.random.default_rng(seed)
+    n_ok = 0
+    for locus in block:
+        idx = nb.fetch_indices(locus.contig, locus.left_flank_coord, locus.right_flank_coord)
+        segs = pb.fetch(locus.contig, locus.left_flank_coord, locus.right_flank_coord)
+        for flank, phred in ((70, 13), (25, 30)):
+            dl, dr = int(rng.integers(0, 6)), int(rng.integers(0, 6))
+            c4 = (locus.left_coord - flank, locus.left_coord - dl, locus.right_coord + dr, locus.right_coord + flank)
+            ex = extract_reads(nb, idx, np.tile(c4, (len(idx), 1)), flank, phred)
+            for k, s in enumerate(segs):
+                c = get_read_coords_from_cigar(*c4, s)
+                if c.is_incomplete():
+                    assert ex["status"][k] == 1
+                    continue
+                try:
+                    sd = get_sequence_data_for_locus(s, c, flank, phred)
+                except LowMeanBaseQual:
+                    assert ex["status"][k] == 2
+                    continue
+                exp = sd.flank_left_seq_wc[-flank:] + sd.tr_seq_wc + sd.flank_right_seq_wc[:flank]
+                assert ex["status"][k] == 0 and ex["seqs"][ex["seq_off"][k]:ex["seq_off"][k + 1]].tobytes().decode() == exp
+                n_ok += 1
+    assert n_ok > 20
