@@ -10,7 +10,7 @@ L = _lib.load()
 t = dict(seqs=torch.from_numpy(b.seqs).to(dev), seq_off=torch.from_numpy(b.seq_off).to(dev), nfl=torch.from_numpy(b.nfl).to(dev), ntr=torch.from_numpy(b.ntr).to(dev), nfr=torch.from_numpy(b.nfr).to(dev), est_cn=torch.from_numpy(b.est_cn).to(dev), read_off=torch.from_numpy(b.read_off).to(dev), motifs=torch.from_numpy(b.motifs).to(dev), motif_off=torch.from_numpy(b.motif_off).to(dev))
 sb = _lib.StrkBatch(n_reads=b.n_reads, n_loci=b.n_loci, **{k: v.data_ptr() for k, v in t.items()})
 p = make_params(); st = _lib.StrkStats()
-D = 3
+D = 4
 ctxs = [_lib.Context(0) for _ in range(D)]; streams = [torch.cuda.Stream(dev) for _ in range(D)]
 outs = [torch.zeros((4, b.n_reads), dtype=torch.int32, device=dev) for _ in range(D)]
 def submit(i):
