@@ -114,6 +114,8 @@ def test_random_batches_and_options_match_the_oracle(gpu_ctx):
             else:
                 reads += _one_count_case(rng, gpu_ctx)
             cases += 1
+            if cases % 40 == 0:
+                print(f"[fuzz seed {seed}] {cases} cases so far", flush=True)
     except AssertionError as e:
         raise AssertionError(f"fuzz seed {seed}, case {cases}: {e}") from e
     print(f"\n[fuzz seed {seed}] {cases} cases, {reads} reads, {pairs} realignments, {loci} reference-side loci in {time.time() - t0:.1f} s")
