@@ -2,7 +2,7 @@
 # default bench under different persistent-grid sizes (STRKIT_AMD_DP_BLOCKS) and pipeline depths
 for cfg in "$@"; do
   blocks=${cfg%%:*}; depth=${cfg##*:}
-  STRKIT_AMD_DP_BLOCKS=$blocks python bench.py --steps 60 --warmup 8 --no-cpu-baseline --pipeline $depth 2>&1 | tail -1 > /tmp/gs.json
+  STRKIT_AMD_DP_BLOCKS=$blocks python bench.py --steps 200 --warmup 24 --no-cpu-baseline --pipeline $depth 2>&1 | tail -1 > /tmp/gs.json
   python3 - "$blocks" "$depth" <<'PY'
 import sys, json
 j = json.load(open("/tmp/gs.json"))
