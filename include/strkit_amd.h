@@ -214,6 +214,11 @@ int strk_realign(strk_ctx* ctx, int32_t n_pairs, const uint8_t* s1, const int64_
 int64_t strk_bam_scan(const uint8_t* buf, int64_t n_bytes, int64_t first_rec, int64_t cap, int64_t* rec_off, int32_t* tid,
                       int32_t* pos, int32_t* end, int32_t* flag, int32_t* l_seq, int32_t* clip_l, int32_t* clip_r);
 
+/* strk_bgzf_inflate: decompresses a whole BGZF stream (BAM, bgzipped FASTA) with n_threads host threads (0 = all
+ * cores); blocks are independent deflate streams, every block's CRC is checked.  out == NULL: returns the decompressed
+ * size.  Otherwise returns the number of bytes written, or a negative STRK_E_* code. */
+int64_t strk_bgzf_inflate(const uint8_t* comp, int64_t n_comp, uint8_t* out, int64_t out_cap, int32_t n_threads);
+
 /* strk_extract_reads: item i = (record at rec_off[i], locus boundaries coords[4i..4i+3] = left_flank_coord, left_coord,
  * right_coord, right_flank_coord).  An item with alt_cigar_off[i+1] > alt_cigar_off[i] uses that CIGAR (BAM encoding)
  * starting at alt_start[i] instead of the record's own alignment (a realigned read); alt_* may be NULL.

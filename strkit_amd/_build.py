@@ -18,7 +18,7 @@ SOURCES = ["strk_api.hip"]
 # every header and include fragment under csrc/ (picked up by name, so that a new one can never be left out of the staleness hash) + the C ABI
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join("..", "..", "include", "strkit_amd.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-Wall", "-Wextra", "-Wno-unused-parameter"]
+               "-Wall", "-Wextra", "-Wno-unused-parameter", "-lz", "-lpthread"]
 
 
 def _hipcc() -> str:

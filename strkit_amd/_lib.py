@@ -47,7 +47,7 @@ class StrkStats(C.Structure):
 EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_repeat_count", "strk_count_loci",
            "strk_count_loci_device", "strk_submit_loci_device", "strk_finish", "strk_score_table",
            "strk_score_ref_table", "strk_ref_repeat_count", "strk_ref_repeat_count_batch", "strk_realign", "strk_bam_scan",
-           "strk_extract_reads")
+           "strk_extract_reads", "strk_bgzf_inflate")
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -114,6 +114,8 @@ def load(build: bool = True):
         L.strk_ref_repeat_count_batch.restype = C.c_int
         L.strk_ref_repeat_count_batch.argtypes = ([C.c_void_p, C.c_int32] + [C.c_void_p] * 9 + [C.c_int32] + [C.c_void_p] * 3
                                                   + [C.c_int32, C.c_void_p])
+        L.strk_bgzf_inflate.restype = C.c_int64
+        L.strk_bgzf_inflate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32]
         L.strk_bam_scan.restype = C.c_int64
         L.strk_bam_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 8
         L.strk_extract_reads.restype = C.c_int

@@ -796,4 +796,30 @@ int strk_extract_reads(const uint8_t* buf, int64_t n_bytes, int32_t n_items, con
     return 0;
 }
 
+int64_t strk_bgzf_inflate(const uint8_t* comp, int64_t n_comp, uint8_t* out, int64_t out_cap, int32_t n_threads) {
+    if (!comp || n_comp < 0) return fail(STRK_E_INVALID, "bad argument");
+    std::vector<strk_fe::BgzfBlock> blocks;
+    int64_t total = 0;
+    if (strk_fe::bgzf_index(comp, n_comp, &blocks, &total)) return fail(STRK_E_INVALID, "not a BGZF stream (or truncated)");
+    if (!out) return total;   // size query
+    if (out_cap < total) return fail(STRK_E_NOMEM, "output buffer too small (%lld < %lld)", (long long)out_cap, (long long)total);
+    const int nt = std::max(1, std::min<int>(n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency(), 32));
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(16);
+            if (i >= blocks.size()) return;
+            for (size_t k = i; k < std::min(blocks.size(), i + 16); ++k)
+                if (!strk_fe::bgzf_inflate_block(comp, blocks[k], out)) bad.store(1);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (bad.load()) return fail(STRK_E_INVALID, "corrupt BGZF block (inflate or CRC failed)");
+    return total;
+}
+
 }  // extern "C"

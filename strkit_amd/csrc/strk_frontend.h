@@ -9,7 +9,10 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
+
+#include <zlib.h>
 
 namespace strk_fe {
 
@@ -106,6 +109,64 @@ inline bool read_coords(const Runs& ix, int64_t lfc, int64_t lc, int64_t rc, int
     out[3] = i_rfe < n ? ix.query_at(i_rfe) : ix.query_at(n - 1) + 1;
     if (out[1] > out[2]) out[2] = out[1];
     return true;
+}
+
+
+// ---- BGZF (the block-gzip container of BAM): independent deflate blocks, so they inflate in parallel ----------------
+struct BgzfBlock {
+    int64_t in_off;    // start of the deflate payload
+    int32_t in_len;    // payload bytes
+    int32_t out_len;   // ISIZE
+    uint32_t crc;
+    int64_t out_off;
+};
+
+// Walks the block headers.  Returns 0 and fills `blocks`, or -1 if the stream is not BGZF / is truncated.
+inline int bgzf_index(const uint8_t* p, int64_t n, std::vector<BgzfBlock>* blocks, int64_t* total) {
+    int64_t off = 0, out = 0;
+    while (off < n) {
+        if (off + 18 > n || p[off] != 0x1f || p[off + 1] != 0x8b || p[off + 2] != 8 || !(p[off + 3] & 4)) return -1;
+        const int xlen = rd_u16(p + off + 10);
+        int64_t x = off + 12;
+        const int64_t xend = x + xlen;
+        int bsize = -1;
+        if (xend > n) return -1;
+        while (x + 4 <= xend) {
+            const int slen = rd_u16(p + x + 2);
+            if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2 && x + 6 <= xend) bsize = rd_u16(p + x + 4);
+            x += 4 + slen;
+        }
+        if (bsize < 0) return -1;
+        const int64_t next = off + bsize + 1;
+        if (next > n || next - 8 < xend) return -1;
+        BgzfBlock b;
+        b.in_off = xend;
+        b.in_len = (int32_t)(next - 8 - xend);
+        b.crc = rd_u32(p + next - 8);
+        b.out_len = (int32_t)rd_u32(p + next - 4);
+        b.out_off = out;
+        if (b.out_len < 0 || b.out_len > 65536) return -1;
+        out += b.out_len;
+        blocks->push_back(b);
+        off = next;
+    }
+    *total = out;
+    return 0;
+}
+
+inline bool bgzf_inflate_block(const uint8_t* p, const BgzfBlock& b, uint8_t* out) {
+    if (b.out_len == 0) return true;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef*>(p + b.in_off);
+    zs.avail_in = (uInt)b.in_len;
+    zs.next_out = out + b.out_off;
+    zs.avail_out = (uInt)b.out_len;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.total_out == (uLong)b.out_len;
+    inflateEnd(&zs);
+    return ok && crc32(crc32(0L, Z_NULL, 0), out + b.out_off, (uInt)b.out_len) == b.crc;
 }
 
 }  // namespace strk_fe

@@ -11,17 +11,31 @@ import numpy as np
 from .. import _lib
 from .bam import AlignedSegment
 
-__all__ = ["NativeBam", "extract_reads", "realign_cigar_to_read_alignment"]
+__all__ = ["NativeBam", "extract_reads", "realign_cigar_to_read_alignment", "bgzf_read"]
 
 _SEQ_LUT = np.frombuffer(b"=ACMGRSVTWYHKDBN", np.uint8)
+
+
+def bgzf_read(path: str, threads: int = 0) -> np.ndarray:
+    """The decompressed content of a BGZF file (all cores: strk_bgzf_inflate); a plain gzip file goes through Python."""
+    comp = np.fromfile(path, np.uint8)
+    L = _lib.load()
+    n = L.strk_bgzf_inflate(comp.ctypes.data, comp.size, None, 0, 0)
+    if n < 0:
+        with gzip.open(path, "rb") as fh:
+            return np.frombuffer(fh.read(), np.uint8)
+    out = np.empty(int(n), np.uint8)
+    got = L.strk_bgzf_inflate(comp.ctypes.data, comp.size, out.ctypes.data, out.size, int(threads))
+    if got < 0:
+        _lib.check(int(got))
+    return out
 
 
 class NativeBam:
     """Decompressed BAM stream + per-record arrays (one C pass); records are addressed by index."""
 
     def __init__(self, path: str):
-        with gzip.open(path, "rb") as fh:
-            self.data = np.frombuffer(fh.read(), np.uint8)
+        self.data = bgzf_read(path)
         raw = self.data
         if raw[:4].tobytes() != b"BAM\x01":
             raise ValueError(f"{path}: not a BAM file")

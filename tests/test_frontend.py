@@ -235,3 +235,32 @@ def test_native_extraction_on_varied_datasets(tmp_path, seed, kw):
                 assert ex["status"][k] == 0 and ex["seqs"][ex["seq_off"][k]:ex["seq_off"][k + 1]].tobytes().decode() == exp
                 n_ok += 1
     assert n_ok > 20
+
+
+def test_parallel_bgzf_inflate(tmp_path):
+    import ctypes as C
+    import gzip
+    from strkit_amd import _lib
+    from strkit_amd.frontend.native import bgzf_read
+    t = make_dataset(str(tmp_path), n_loci=20, reads_per_locus=10, read_len=4000, seed=8, sub=0.01, indel=0.01)
+    path = t["paths"]["bam"]
+    with gzip.open(path, "rb") as fh:
+        want = np.frombuffer(fh.read(), np.uint8)
+    for threads in (0, 1, 3):
+        assert np.array_equal(bgzf_read(path, threads), want)
+    # a flipped payload byte is caught by the block's CRC (or by inflate itself)
+    comp = np.fromfile(path, np.uint8).copy()
+    L = _lib.load()
+    n = L.strk_bgzf_inflate(comp.ctypes.data, comp.size, None, 0, 0)
+    assert n == want.size
+    comp[comp.size // 2] ^= 0x5A
+    out = np.empty(int(n), np.uint8)
+    assert L.strk_bgzf_inflate(comp.ctypes.data, comp.size, out.ctypes.data, out.size, 2) < 0
+    assert b"BGZF" in L.strk_last_error()
+    # a plain gzip file is not BGZF: the reader falls back to Python's gzip
+    plain = str(tmp_path / "plain.gz")
+    with gzip.open(plain, "wb") as fh:
+        fh.write(want[:5000].tobytes())
+    raw = np.fromfile(plain, np.uint8)
+    assert L.strk_bgzf_inflate(raw.ctypes.data, raw.size, None, 0, 0) < 0
+    assert np.array_equal(bgzf_read(plain), want[:5000])
