@@ -28,6 +28,15 @@ def main(argv=None) -> int:
     c.add_argument("--max-rcn-iters", type=int, default=50)
     c.add_argument("--min-read-align-score", type=float, default=0.1)
     a = ap.parse_args(argv)
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:   # python -m torch.distributed.run --nproc-per-node N -m strkit_amd call ...: one rank per GPU
+        import torch
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        os.environ.setdefault("STRKIT_AMD_DEVICE", str(local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from .frontend import call_sample, write_json
     from .repeat_count_params import RepeatCountParams
     rc = RepeatCountParams("repalign", a.max_rcn_iters, 3, 1)   # params.py:26-27,45
@@ -35,6 +44,12 @@ def main(argv=None) -> int:
                       min_avg_phred=a.min_avg_phred, max_reads=a.max_reads, respect_ref=a.respect_ref,
                       sample_id=a.sample_id, processes=a.processes, rc_params=rc,
                       min_read_align_score=a.min_read_align_score)
+    if world > 1:
+        import torch.distributed as dist
+        rank0 = dist.get_rank() == 0
+        dist.destroy_process_group()
+        if not rank0:
+            return 0
     if a.json == "-":
         import json
         json.dump(rep, sys.stdout, indent=1)

@@ -26,7 +26,7 @@ from .fasta import Fasta
 from .loci import Locus, load_loci
 from .native import NativeBam, extract_reads, realign_cigar_to_read_alignment
 
-__all__ = ["call_sample", "call_locus", "call_blocks", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
+__all__ = ["call_sample", "call_locus", "call_blocks", "call_blocks_sharded", "deal_locus_blocks", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
 
 MAX_READS = 250                 # params.max_reads default (strkit/call/params.py:21)
 DEFAULT_REF_MAX_ITERS = 100     # call_locus.py: default_ref_max_iters
@@ -78,6 +78,14 @@ def get_locus_with_ref_data(locus: Locus, ref: Fasta, respect_ref: bool = False,
     return get_loci_with_ref_data([locus], ref, respect_ref, context)[0]
 
 
+def _distributed() -> bool:
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:  # noqa: BLE001
+        return False
+
+
 def _locus_dict(locus: Locus) -> dict:
     """STRkitLocus.to_dict() + the always-present call keys (call_locus.py:1013-1017, json_report.py:69-74)."""
     return {"locus_index": locus.t_idx, "locus_id": locus.locus_id, "contig": locus.contig, "start": locus.left_coord,
@@ -103,8 +111,15 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
     ref = Fasta(ref) if isinstance(ref, str) else ref
     t0 = time.perf_counter()
     blocks = load_loci(loci_file, flank_size, contigs=set(bam.references) & set(ref.references), processes=processes)
-    results, n_depth, tm = call_blocks(blocks, bam, ref, flank_size, realign, min_avg_phred, max_reads, respect_ref,
-                                       rc_params, min_read_align_score, ctx)
+
+    def run(bl):
+        return call_blocks(bl, bam, ref, flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params,
+                           min_read_align_score, ctx)
+
+    if _distributed():          # launched under torch.distributed (one rank per GPU): shard the blocks
+        results, n_depth, tm = call_blocks_sharded(blocks, run)
+    else:
+        results, n_depth, tm = run(blocks)
     # same top-level layout as the reference's report (strkit/call/output/json_report.py:37-60,127-154)
     return {"sample_id": sample_id,
             "caller": {"name": "strkit_amd", "version": _lib.load().strk_version().decode()},
@@ -116,6 +131,38 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
             "results": results,
             "avg_read_depth": n_depth / max(1, sum(1 for r in results if "reads" in r)),
             "runtime": time.perf_counter() - t0, "stage_times": {k: round(v, 4) for k, v in tm.items()}}
+
+
+def deal_locus_blocks(blocks: list[list[Locus]], world: int) -> list[list[int]]:
+    """Deterministic longest-processing-time dealing of locus blocks to `world` ranks (indices into `blocks`),
+    balanced by an estimate of the DP work: sum over loci of (tract + flanks) squared."""
+    cost = [sum((l.right_coord - l.left_coord + 2 * l.flank_size) ** 2 for l in blk) for blk in blocks]
+    load = [0] * world
+    owner: list[list[int]] = [[] for _ in range(world)]
+    for k in sorted(range(len(blocks)), key=lambda i: (-cost[i], i)):
+        r = load.index(min(load))
+        owner[r].append(k)
+        load[r] += cost[k]
+    return [sorted(o) for o in owner]
+
+
+def call_blocks_sharded(blocks, call_fn) -> tuple[list[dict], int, dict]:
+    """One process per GPU (`--processes N` of the reference <-> N ranks of a torch.distributed job): every rank calls
+    its share of the locus blocks with `call_fn(blocks) -> (results, reads kept, stage times)` and all ranks get the
+    merged results ordered by locus index, as the reference's ordered merge does (call_sample.py:195-197,420).
+    The only communication is this collection of per-locus results."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = [blocks[k] for k in deal_locus_blocks(blocks, world)[rank]]
+    results, n_depth, tm = call_fn(mine) if mine else ([], 0, {})
+    gathered: list = [None] * world
+    dist.all_gather_object(gathered, (results, n_depth, tm))
+    merged = sorted((r for part, _, _ in gathered for r in part), key=lambda r: r["locus_index"])
+    stage = {}
+    for _, _, t in gathered:
+        for k, v in t.items():
+            stage[k] = max(stage.get(k, 0.0), v)        # ranks run side by side: the slowest one counts
+    return merged, sum(n for _, n, _ in gathered), stage
 
 
 def call_blocks(blocks, bam: BamFile, ref: Fasta, flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params,

@@ -184,3 +184,49 @@ def test_adjusted_score_and_read_filters_follow_the_callers_loop():
             assert got["keep"][r] and abs(got["sc"][r] - adj) < 1e-12
         assert bool(got["locus_ok"][l]) == ok
     assert (~got["locus_ok"]).any() and got["locus_ok"].any()
+
+
+def _gloo_call_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from strkit_amd.frontend.call import call_blocks_sharded
+    from strkit_amd.frontend.loci import Locus
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    blocks = [[Locus(10 * k + i + 1, f"l{10 * k + i}", "chr1", 1000 * (10 * k + i), 1000 * (10 * k + i) + 30 * (1 + (k * 7 + i) % 9), "CAG")
+               for i in range(1 + k % 4)] for k in range(11)]
+
+    def fake_call(mine):      # stands in for the device path: one record per locus, tagged with the rank that made it
+        return [{"locus_index": l.t_idx, "rank": rank} for blk in mine for l in blk], sum(len(b) for b in mine), {"count_s": 0.1 * (rank + 1)}
+
+    merged, n, tm = call_blocks_sharded(blocks, fake_call)
+    q.put((rank, [r["locus_index"] for r in merged], sorted({r["rank"] for r in merged}), n, tm))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_call_driver_shards_locus_blocks_over_two_ranks():
+    """world_size-2 gloo: blocks are dealt to ranks, every rank ends with all loci in catalog order."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from strkit_amd.frontend.call import deal_locus_blocks
+    from strkit_amd.frontend.loci import Locus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_call_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_loci = sum(1 + k % 4 for k in range(11))
+    for rank, order, ranks_seen, n, tm in got:
+        assert order == sorted(order) and len(order) == n_loci and ranks_seen == [0, 1] and n == n_loci
+        assert abs(tm["count_s"] - 0.2) < 1e-9
+    blocks = [[Locus(i + 1, "x", "chr1", 0, 100 * (i + 1), "CAG")] for i in range(7)]
+    shares = deal_locus_blocks(blocks, 3)
+    assert sorted(k for s_ in shares for k in s_) == list(range(7)) and shares == deal_locus_blocks(blocks, 3)
+    assert shares[0][-1] == 6     # the heaviest block goes to the first rank
