@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — reads/s through the per-read repeat-count hot path on MI355X.
 
-One "step" = one pass of the hot path (plan -> DP kernels -> search replay) over one batch of
-synthetic reads that is already resident in HBM: BASELINE.json configs[1]
-(1 000 loci x 30 HiFi reads, motif 3-6 bp, 70 bp flanks).  With --gpus N every rank owns its own
-shard of N x 1 000 loci (weak scaling, loci are independent: strkit/call/call_sample.py:414) and
-the per-read results are collected with one RCCL all-gather per step.
+One "step" = one pass of the hot path (hash -> plan -> banded / exact DP kernels -> search replay with the caller's
+start-count feedback) over one batch of synthetic reads that is already resident in HBM.  The default workload is
+BASELINE.json configs[1]'s shape at north_star's size: 10 000 loci x 30 HiFi reads (motif 3-6 bp, 70 bp flanks) per
+step and GPU, built from ten independent instances of the 1 000-locus config.  EIGHT distinct batches (different
+seeds) rotate through the timed region, so that nothing adaptive inside the library (candidate-window level, band
+probation, history-sized grids) is replaying one input.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W [--strong --config 4|5]
+
+Default (weak scaling): every rank owns its own batches; the per-read results of every step are collected on every
+rank with one RCCL all-gather per `--gather-every` steps.  --strong: ONE catalog (the named config at its full size)
+is dealt to the ranks in blocks of <= 200 loci balanced by estimated DP cells (strkit/call/loci.py:193,
+call_sample.py:414), every rank counts its share each step, fixed-size per-read records are all-gathered and rank 0
+checks the gathered table against the one-rank table bit for bit.
 
 Rank 0 prints ONE JSON line (contract in the task statement; extra keys documented in DESIGN.md §6).
 """
@@ -22,8 +29,8 @@ import os
 import sys
 import time
 
-# Four calls in flight use four HIP streams besides the default one; the runtime's default of 4 hardware queues would
-# make two of them share a queue (and serialise).  Read by the HIP runtime at its initialisation, so set before it.
+# Calls in flight use one HIP stream each besides the default one; the runtime's default of 4 hardware queues would make
+# two of them share a queue (and serialise).  Read by the HIP runtime at its initialisation, so set before it.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
@@ -32,10 +39,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-# int32 VALU peak used for the companion figure: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 Tops/s
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-WORKLOAD = ("cfg2: 1000 loci x 30 HiFi reads per GPU, motif 3-6 bp, flank 70; exact scores "
-            "(128/256-diagonal banded pass with exactness certificate, exact fall-back)")
+N_SIMD = 256 * 4
+# Measured on MI355X (profiles/r02_valu_rate.txt, tools/valu_rate.hip): v_max3_i32, v_add_u32_sdwa, v_perm_b32,
+# v_alignbyte_b32, v_mov_b32_dpp, v_pk_*_i16 issue at one wave-instruction per 4.2 SIMD cycles at every occupancy
+# (half rate: 16 lanes per clock); only plain v_add_u32 / v_add_f32 approach the SIMD-32 rate (2.3-2.6 cycles).
+VALU_CYCLES_PER_INST = 4.2
+DP_INSTS_PER_CELL_FLOOR = 2.25      # v_add_u32_sdwa + v_max3_i32 per cell + one v_perm_b32 per four cells
+PROFILE_TAG = "r02"                 # profiles/<tag>_pmc_summary.json holds the PMC passes of this same command
+UNIT_LOCI = 1000                    # one instance of a BASELINE config 2 / 3 batch
+
+
+def _gen_worker(args):
+    cfg, n_loci, seed_shift = args
+    from strkit_amd.synth import make_config
+    return make_config(cfg, n_loci=n_loci, seed_shift=seed_shift)
+
+
+def make_batches(cfg: int, n_loci: int, n_batches: int, rank: int, pool) -> list:
+    """`n_batches` distinct batches of `n_loci` loci of config `cfg`: each is the concatenation of independent
+    instances of <= 1 000 loci (seed shifts unique per rank, batch and instance), generated on all host cores."""
+    from strkit_amd.synth import LocusBatch
+    per = [min(UNIT_LOCI, n_loci - k) for k in range(0, n_loci, UNIT_LOCI)]
+    jobs = [(cfg, n, (rank * 64 + b) * 1024 + j) for b in range(n_batches) for j, n in enumerate(per)]
+    parts = pool.map(_gen_worker, jobs) if pool is not None else [_gen_worker(j) for j in jobs]
+    return [LocusBatch.concat(parts[b * len(per):(b + 1) * len(per)]) for b in range(n_batches)]
 
 
 def _cpu_worker(args):
@@ -55,43 +82,51 @@ def _cpu_worker(args):
     return b.n_reads, time.perf_counter() - t0, cells
 
 
-def cpu_baseline(cfg: int, sample_loci: int) -> dict:
-    """Oracle (CPU restatement of the reference algorithm) on a bounded sample, all host cores,
-    loci sharded over processes as strkit/call/call_sample.py:414 does.  Runs BEFORE HIP is
-    initialised so the forked workers never see a GPU context."""
-    import multiprocessing as mp
-    import oracle
-    oracle.build()
-    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+def cpu_baseline(cfg: int, sample_loci: int, pool, cores: int) -> dict:
+    """Oracle (CPU restatement of the reference algorithm) on a bounded sample, all host cores, loci sharded over
+    processes as strkit/call/call_sample.py:414 does.  Runs BEFORE HIP is initialised so the forked workers never
+    see a GPU context."""
     per = max(1, sample_loci // cores)
     jobs = [(cfg, i * per, (i + 1) * per, 0) for i in range(cores)]
     t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, jobs)
+    res = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
     reads = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
     return {"value": reads / busy, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {per * cores} loci ({reads} reads) of the same workload, scalar C oracle with the reference's "
-                      f"per-locus memoisation, {cores} processes, {busy:.1f} s busy each "
+            "sample": f"first {per * cores} loci ({reads} reads) of one 1 000-locus instance of the workload, scalar C oracle "
+                      f"with the reference's per-locus memoisation, {cores} processes, {busy:.1f} s busy each "
                       f"({busy * cores:.0f} core-seconds; {wall:.1f} s wall incl. input generation)",
             "reads_per_s_per_core": reads / busy / cores, "gcups": sum(r[2] for r in res) / busy / 1e9}
+
+
+def pmc_summary(kernel: str) -> dict | None:
+    """Per-launch PMC readings of `kernel` from the committed rocprofv3 passes of this same command
+    (profiles/README.md; separate --pmc passes, FETCH_SIZE / WRITE_SIZE in KiB)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary.json")) as f:
+            return json.load(f)[kernel]
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", type=int, default=2)
-    ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's own count)")
+    ap.add_argument("--loci", type=int, default=None, help="loci per step (weak: per GPU; strong: of the whole catalog)")
+    ap.add_argument("--batches", type=int, default=8, help="distinct resident batches that rotate through the steps")
+    ap.add_argument("--strong", action="store_true", help="one catalog dealt to the ranks (strong scaling), gathered table checked")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--no-dedupe", action="store_true", help="score identical reads of a locus separately")
     ap.add_argument("--no-band", action="store_true", help="exact kernels only (no banded first pass)")
-    ap.add_argument("--gather-every", type=int, default=8, help="steps per result all-gather when several ranks run")
+    ap.add_argument("--gather-every", type=int, default=4, help="steps per result all-gather when several ranks run")
     ap.add_argument("--pipeline", type=int, default=4, help="batched calls in flight (contexts/streams)")
     ap.add_argument("--cpu-sample-loci", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the pipeline-1 and host-buffer (PCIe-inclusive) sub-results")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (self-test)")
     a = ap.parse_args()
 
@@ -102,16 +137,28 @@ def main() -> None:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
+    default_loci = {1: 44, 2: 10000, 3: 10000, 4: 170000 if a.strong else 21250, 5: 2000 if a.strong else 250}
+    n_loci = a.loci or default_loci[a.config]
 
+    # ---- host-side preparation in forked workers, BEFORE HIP is initialised --------------------------------------
+    import multiprocessing as mp
+    cores = max(1, min(16, len(os.sched_getaffinity(0)) // max(1, min(world, 8))))
     cpu = None
-    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.config, a.cpu_sample_loci)
+    with mp.get_context("fork").Pool(cores) as pool:
+        if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+            import oracle
+            oracle.build()
+            cpu = cpu_baseline(a.config, a.cpu_sample_loci, pool, cores)
+        if a.strong:
+            catalog = make_batches(a.config, n_loci, 1, 0, pool)[0]      # the same catalog on every rank
+        else:
+            batches = make_batches(a.config, n_loci, max(1, a.batches), rank, pool)
 
     import torch
     import torch.distributed as dist
     from strkit_amd import _lib
-    from strkit_amd.batch import make_params
-    from strkit_amd.synth import make_config
+    from strkit_amd.batch import batch_struct, make_params
+    from strkit_amd.sharding import deal_blocks, select_loci
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -121,46 +168,61 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # ---- this rank's shard: its own loci (weak scaling), inputs made resident in HBM -----------
-    b = make_config(a.config, n_loci=a.loci, seed_shift=rank)
+    if a.strong:    # this rank's share of the one catalog, and where its reads sit in the whole table
+        shares = deal_blocks(catalog, world)
+        mine, my_reads = select_loci(catalog, shares[rank])
+        batches = [mine]
+        n_pad = max(int(sum(catalog.read_off[l + 1] - catalog.read_off[l] for l in s)) for s in shares)
     L = _lib.load()
-    t = dict(seqs=torch.from_numpy(b.seqs).to(dev), seq_off=torch.from_numpy(b.seq_off).to(dev),
-             nfl=torch.from_numpy(b.nfl).to(dev), ntr=torch.from_numpy(b.ntr).to(dev),
-             nfr=torch.from_numpy(b.nfr).to(dev), est_cn=torch.from_numpy(b.est_cn).to(dev),
-             read_off=torch.from_numpy(b.read_off).to(dev), motifs=torch.from_numpy(b.motifs).to(dev),
-             motif_off=torch.from_numpy(b.motif_off).to(dev))
-    sb = _lib.StrkBatch(n_reads=b.n_reads, n_loci=b.n_loci, **{k: v.data_ptr() for k, v in t.items()})
+
+    def resident(b):
+        t = dict(seqs=torch.from_numpy(b.seqs).to(dev), seq_off=torch.from_numpy(b.seq_off).to(dev),
+                 nfl=torch.from_numpy(b.nfl).to(dev), ntr=torch.from_numpy(b.ntr).to(dev),
+                 nfr=torch.from_numpy(b.nfr).to(dev), est_cn=torch.from_numpy(b.est_cn).to(dev),
+                 read_off=torch.from_numpy(b.read_off).to(dev), motifs=torch.from_numpy(b.motifs).to(dev),
+                 motif_off=torch.from_numpy(b.motif_off).to(dev))
+        return t, _lib.StrkBatch(n_reads=b.n_reads, n_loci=b.n_loci, **{k: v.data_ptr() for k, v in t.items()})
+
+    res_b = [resident(b) for b in batches]
+    NB = len(batches)
+    n_reads_max = max(b.n_reads for b in batches)
+    rows = n_pad if a.strong else n_reads_max       # result columns per step (strong: padded to the largest share)
     p = make_params(window=a.window, dedupe=not a.no_dedupe, band=not a.no_band)
     st = _lib.StrkStats()
-    # D steps in flight: one context (workspace) + one HIP stream + one output buffer per slot, so
-    # the tail of one batch overlaps the head of the next (successive locus blocks of a real run).
+    # D steps in flight: one context (workspace) + one HIP stream per slot, so the head of one batch (hash, plan: latency
+    # bound) overlaps the tail of the previous one (successive locus blocks of a real run).
     D = max(1, a.pipeline)
     ctxs = [_lib.Context(local_rank) for _ in range(D)]
     streams = [torch.cuda.Stream(dev) for _ in range(D)]
-    outs = [torch.zeros((4, b.n_reads), dtype=torch.int32, device=dev) for _ in range(D)]  # cn | score | n_iters | start
-    # Results of every step are collected on every rank (RCCL all-gather over xGMI), G steps per collective: the
-    # reference merges its workers' results once per contig (call_sample.py:195-197,420), not once per locus block.
-    # The kernels write straight into the staging buffer of their round (two buffers: steps of the next round are in
-    # flight while a round is being gathered), so collecting costs no extra copy.
-    G = max(D, a.gather_every)
-    stage = torch.zeros((2, G * 4, b.n_reads), dtype=torch.int32, device=dev) if use_dist else None
-    gathered = torch.zeros((world * G * 4, b.n_reads), dtype=torch.int32, device=dev) if use_dist else None
+    # Results: per step five int32 rows (read index | cn | score | n_iters | start).  With several ranks the kernels
+    # write straight into the staging buffer of their gather round (two buffers: the next round is in flight while one
+    # is being gathered) and ONE RCCL all-gather per G steps collects the fixed-size records on every rank (the
+    # reference merges its workers' results once per contig, call_sample.py:195-197,420, not once per locus block).
+    G = max(D, a.gather_every) if use_dist else D
+    NF = 5
+    stage = torch.full((2, G * NF, rows), -1, dtype=torch.int32, device=dev)
+    gathered = torch.zeros((world * G * NF, rows), dtype=torch.int32, device=dev) if use_dist else None
+    if a.strong:
+        stage[:, 0::NF, :len(my_reads)] = torch.from_numpy(my_reads.astype(np.int32)).to(dev)
+    else:
+        stage[:, 0::NF, :] = torch.arange(rows, dtype=torch.int32, device=dev)
+
+    def batch_of(i):
+        return (i + i // D) % NB        # every context sees every batch
 
     def out_of(i):
-        if not use_dist:
-            return outs[i % D]
-        j = i % G
-        return stage[(i // G) % 2, 4 * j:4 * j + 4]
+        return stage[(i // G) % 2, NF * (i % G):NF * (i % G) + NF]
 
-    acc = dict(dp_ms=0.0, band_ms=0.0, all_ms=0.0, misses=0, fallback=0, dedup=0, band=0, band_fb=0, n=0)
+    acc = dict(dp_ms=0.0, band_ms=0.0, all_ms=0.0, misses=0, fallback=0, dedup=0, band=0, band_fb=0, n=0, reads=0, loci=0,
+               band_bytes=0, exact_bytes=0, cells=0, windows=set())
 
     def submit(i):
         k = i % D
         if use_dist and i % G < D:   # first use of this stream in a round: the collective that last read the round's buffer is done
             streams[k].wait_stream(torch.cuda.current_stream(dev))
         o = out_of(i)
-        _lib.check(L.strk_submit_loci_device(ctxs[k].handle, C.byref(sb), C.byref(p), o[0].data_ptr(), o[1].data_ptr(),
-                                             o[2].data_ptr(), o[3].data_ptr(), C.c_void_p(streams[k].cuda_stream)))
+        _lib.check(L.strk_submit_loci_device(ctxs[k].handle, C.byref(res_b[batch_of(i)][1]), C.byref(p), o[1].data_ptr(),
+                                             o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(), C.c_void_p(streams[k].cuda_stream)))
 
     def finish(i, timed):
         k = i % D
@@ -169,7 +231,10 @@ def main() -> None:
             acc["dp_ms"] += st.dp_kernel_ms; acc["band_ms"] += st.band_kernel_ms; acc["all_ms"] += st.kernel_ms
             acc["band"] += st.n_band_reads; acc["band_fb"] += st.n_band_fallback
             acc["misses"] += st.n_miss_reads; acc["fallback"] += st.n_fallback; acc["dedup"] += st.n_dedup_reads
+            acc["band_bytes"] += st.band_bytes; acc["exact_bytes"] += st.exact_bytes; acc["cells"] += st.dp_cells
+            acc["windows"].add(int(st.window_used))
             acc["n"] += 1
+            acc["reads"] += batches[batch_of(i)].n_reads; acc["loci"] += batches[batch_of(i)].n_loci
         if use_dist and (i + 1) % G == 0:  # a round is complete: collect it from every shard
             dist.all_gather_into_tensor(gathered, stage[(i // G) % 2])
 
@@ -192,9 +257,9 @@ def main() -> None:
             dist.all_gather_into_tensor(gathered, stage[((n_steps - 1) // G) % 2])
 
     # One-time set-up, outside the W warm-up steps the caller asked for: the first call of every context allocates its
-    # workspace (0.4 GB of scratch) and tries the band on a sample of the reads, and the library settles the default
-    # candidate window after eight calls without a miss -- none of which belongs to a steady-state step.
-    prime = 4 * D
+    # workspace and tries the band on a sample of the reads, and the library settles the default candidate window after
+    # eight calls without a miss -- none of which belongs to a steady-state step.
+    prime = max(3 * D, 12)
     run(prime, False)
     flush(prime)
     fence()
@@ -206,93 +271,154 @@ def main() -> None:
     flush(a.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    dp_ms, all_ms, misses, fallback = acc["dp_ms"], acc["all_ms"], acc["misses"], acc["fallback"]
-    out = out_of(a.steps - 1).clone()
+    last = a.steps - 1
+    out_last = out_of(last).clone()
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([b.n_reads, b.n_loci], dtype=torch.int64, device=dev)
+        tot = torch.tensor([acc["reads"], acc["loci"]], dtype=torch.int64, device=dev)
         dist.all_reduce(tot)
-        n_reads_all, n_loci_all = int(tot[0]), int(tot[1])
+        reads_all, loci_all = int(tot[0]), int(tot[1])
     else:
-        n_reads_all, n_loci_all = b.n_reads, b.n_loci
-    # un-overlapped duration of one call, for reference (outside the timed region)
-    iso_dp, iso_band, iso_all = 0.0, 0.0, 0.0
-    for _ in range(5):
-        submit(0); finish(0, False)
-        iso_dp += st.dp_kernel_ms / 5; iso_band += st.band_kernel_ms / 5; iso_all += st.kernel_ms / 5
-    band_bytes, exact_bytes = int(st.band_bytes), int(st.exact_bytes)
+        reads_all, loci_all = acc["reads"], acc["loci"]
+
+    # ---- sub-results outside the timed region (rank 0 of a one-GPU run) -------------------------------------------
+    extras = {}
+    if rank == 0 and world == 1 and not a.no_extras:
+        # (a) one call at a time on one context: no overlap between calls; its per-kernel durations are un-overlapped
+        n1 = max(4, min(a.steps, 16))
+        iso = dict(dp=0.0, band=0.0, all=0.0)
+        fence()
+        t1 = time.perf_counter()
+        r1 = 0
+        for i in range(n1):
+            o = out_of(i)
+            _lib.check(L.strk_submit_loci_device(ctxs[0].handle, C.byref(res_b[i % NB][1]), C.byref(p), o[1].data_ptr(), o[2].data_ptr(),
+                                                 o[3].data_ptr(), o[4].data_ptr(), C.c_void_p(streams[0].cuda_stream)))
+            _lib.check(L.strk_finish(ctxs[0].handle, C.byref(st)))
+            iso["dp"] += st.dp_kernel_ms / n1; iso["band"] += st.band_kernel_ms / n1; iso["all"] += st.kernel_ms / n1
+            r1 += batches[i % NB].n_reads
+        fence()
+        e1 = time.perf_counter() - t1
+        extras["pipeline1"] = {"value": r1 / e1, "unit": "reads/s", "ms_per_step": e1 / n1 * 1e3, "steps": n1,
+                               "k_dp_band_ms": iso["band"], "k_dp_all_ms": iso["dp"], "device_ms": iso["all"],
+                               "note": "one call at a time: kernel durations are un-overlapped"}
+        # (b) the host-buffer entry point strk_count_loci: H2D of the batch + D2H of the results inside every step
+        nh = max(2, min(a.steps, 6))
+        hb = [batch_struct(b) for b in batches[:min(NB, 3)]]
+        outs = [np.zeros(n_reads_max, np.int32) for _ in range(4)]
+        for w in range(1 + nh):
+            if w == 1:
+                t2 = time.perf_counter()
+                r2 = 0
+            s, _keep = hb[w % len(hb)]
+            _lib.check(L.strk_count_loci(ctxs[0].handle, C.byref(s), C.byref(p), *[o.ctypes.data for o in outs], C.byref(st)))
+            if w >= 1:
+                r2 += batches[w % len(hb)].n_reads
+        e2 = time.perf_counter() - t2
+        extras["h2d_inclusive"] = {"value": r2 / e2, "unit": "reads/s", "ms_per_step": e2 / nh * 1e3, "steps": nh,
+                                   "note": "strk_count_loci with pageable host buffers in and out, one call at a time "
+                                           "(PCIe + staging copies inside the step); never the headline value"}
     fence()
 
-    def pmc_traffic(kernel):
-        """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-        (profiles/README.md): FETCH_SIZE and WRITE_SIZE are in KiB and were collected in separate passes;
-        FETCH_SIZE is doubled, the guide's gfx950 correction (calibrated here on k_hash, which reads every
-        input byte exactly once: raw FETCH_SIZE = 0.49 x bytes)."""
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_f_pmc_summary.json")) as f:
-                k = json.load(f)[kernel]
-            return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-        except Exception:  # noqa: BLE001
-            return None
+    strong_check = None
+    if a.strong and rank == 0:
+        # the gathered table of the last step against this rank counting the WHOLE catalog alone, bit for bit
+        j = last % G
+        if use_dist:
+            g = gathered.view(world, G * NF, rows)[:, NF * j:NF * j + NF].cpu().numpy()
+        else:
+            g = out_last.cpu().numpy()[None]
+        table = np.full((4, catalog.n_reads), -(1 << 30), np.int32)
+        for w in range(g.shape[0]):
+            idx = g[w, 0]
+            ok = idx >= 0
+            table[:, idx[ok]] = g[w, 1:5][:, ok]
+        _t, sb_all = resident(catalog)
+        one = torch.zeros((4, catalog.n_reads), dtype=torch.int32, device=dev)
+        _lib.check(L.strk_count_loci_device(ctxs[0].handle, C.byref(sb_all), C.byref(p), one[0].data_ptr(), one[1].data_ptr(),
+                                            one[2].data_ptr(), one[3].data_ptr(), None, C.byref(st)))
+        strong_check = "identical" if np.array_equal(table, one.cpu().numpy()) else "MISMATCH"
 
     if rank == 0:
-        # sanity: the timed path's answers on the first loci agree with the oracle (checker only)
+        # sanity: the timed path's answers on the first loci of the last step agree with the oracle (checker only)
         import oracle
-        chk = b.locus_slice(0, min(8, b.n_loci))
-        got = out[:, :chk.n_reads].cpu().numpy()
+        bl = batches[batch_of(last)]
+        chk = bl.locus_slice(0, min(8, bl.n_loci))
+        got = out_last[1:5, :chk.n_reads].cpu().numpy()
         parity = "ok"
         for l in range(chk.n_loci):
-            r0, r1 = int(chk.read_off[l]), int(chk.read_off[l + 1])
+            r0, r1_ = int(chk.read_off[l]), int(chk.read_off[l + 1])
             s0 = int(chk.seq_off[r0])
-            o = oracle.count_locus(chk.seqs[s0:int(chk.seq_off[r1])], chk.seq_off[r0:r1 + 1] - s0, chk.nfl[r0:r1],
-                                   chk.ntr[r0:r1], chk.nfr[r0:r1], chk.est_cn[r0:r1], chk.motif(l))
+            o = oracle.count_locus(chk.seqs[s0:int(chk.seq_off[r1_])], chk.seq_off[r0:r1_ + 1] - s0, chk.nfl[r0:r1_],
+                                   chk.ntr[r0:r1_], chk.nfr[r0:r1_], chk.est_cn[r0:r1_], chk.motif(l))
             for i, k in enumerate(("cn", "score", "n_iters", "start")):
-                if not np.array_equal(got[i, r0:r1], o[k]):
+                if not np.array_equal(got[i, r0:r1_], o[k]):
                     parity = f"MISMATCH locus {l} field {k}"
         # the dominant kernel of the timed region: the banded kernel when most reads certify, else k_dp_all
-        band_ms = acc["band_ms"]
-        if band_ms > dp_ms:
-            kname, k_ms, alg_bytes = "k_dp_band", band_ms / a.steps, band_bytes
+        n = max(1, acc["n"])
+        if acc["band_ms"] > acc["dp_ms"]:
+            kname, k_ms, alg_bytes = "k_dp_band", acc["band_ms"] / n, acc["band_bytes"] / n
         else:
-            kname, k_ms, alg_bytes = "k_dp_all", dp_ms / a.steps, exact_bytes
+            kname, k_ms, alg_bytes = "k_dp_all", acc["dp_ms"] / n, acc["exact_bytes"] / n
         dp_s = max(k_ms, 1e-9) / 1e3
-        all_dp_s = max(dp_ms + band_ms, 1e-9) / a.steps / 1e3
-        cells = int(st.dp_cells)
+        pmc = pmc_summary(kname) if (a.config == 2 and a.loci is None and not a.no_dedupe and not a.no_band and not a.strong) else None
+        roof = {"bound": "hbm", "achieved": alg_bytes / dp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / dp_s / 1e9 / HBM_PEAK_GBS,
+                "traffic": (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if pmc else None,
+                "kernel": "strk::" + kname, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "integer max-plus DP: what binds is VALU issue, not HBM (valu_* keys); kernel_ms is the HIP-event duration "
+                        "of the kernel inside the timed region, where calls_in_flight launches share the device (pipeline1 holds "
+                        "the un-overlapped duration); algorithmic bytes = (|window| + 16) per read this kernel scored"}
+        if pmc and "SQ_INSTS_VALU" in pmc:
+            clock_ghz = pmc.get("clock_ghz", 2.3)
+            floor_ms = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / N_SIMD / (clock_ghz * 1e9) * 1e3
+            un_ms = extras.get("pipeline1", {}).get("k_dp_band_ms" if kname == "k_dp_band" else "k_dp_all_ms") or k_ms
+            cells_launch = pmc.get("cells_per_launch") or acc["cells"] / n
+            roof.update({"valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES_PER_INST,
+                         "valu_clock_ghz": clock_ghz, "floor_ms": floor_ms, "unoverlapped_kernel_ms": un_ms,
+                         "frac_valu": floor_ms / un_ms,
+                         "insts_per_cell": pmc["SQ_INSTS_VALU"] * 64.0 / cells_launch,
+                         "insts_per_cell_floor": DP_INSTS_PER_CELL_FLOOR,
+                         "frac_of_cell_floor": (cells_launch / 64.0 * DP_INSTS_PER_CELL_FLOOR * VALU_CYCLES_PER_INST / N_SIMD
+                                                / (clock_ghz * 1e9) * 1e3) / un_ms})
+        b0 = batches[0]
+        wl = (f"cfg{a.config} shape" + (" (1000 loci x 30 HiFi reads, motif 3-6 bp, flank 70)" if a.config == 2 else "") +
+              (f": ONE catalog of {catalog.n_loci} loci dealt to {world} rank(s) in blocks of <= 200 loci by estimated cells" if a.strong else
+               f", {b0.n_loci} loci x {b0.n_reads // max(1, b0.n_loci)} reads per step and GPU, {NB} distinct resident batches in rotation") +
+              "; exact scores (banded first pass with exactness certificate, exact fall-back)")
         line = {
-            "metric": "reads/sec realigned", "value": n_reads_all * a.steps / elapsed, "unit": "reads/s",
+            "metric": "reads/sec realigned", "value": reads_all / elapsed, "unit": "reads/s",
             "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": WORKLOAD if a.config == 2 and a.loci is None else f"cfg{a.config}, {b.n_loci} loci per GPU",
-                       "loci_per_gpu": b.n_loci, "reads_per_gpu": b.n_reads, "window": int(p.window) or 8,
+            "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": wl, "loci_per_step_per_gpu": b0.n_loci, "reads_per_step_per_gpu": b0.n_reads,
+                       "distinct_batches": NB, "window": sorted(acc["windows"]),
                        "parallelism": f"loci-sharded x{a.gpus}" + (f" + all_gather every {G} steps" if use_dist else ""),
                        "calls_in_flight": D},
-            "loci_per_s": n_loci_all * a.steps / elapsed,
-            "roofline": {"bound": "hbm", "achieved": alg_bytes / dp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg_bytes / dp_s / 1e9 / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(kname) if (a.config == 2 and a.loci is None and not a.no_dedupe and not a.no_band) else None,
-                         "kernel": "strk::" + kname,
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "whole_path_algorithmic_bytes_per_step": b.algorithmic_bytes(),
-                         "note": "integer max-plus DP: the binding unit is VALU issue (see valu); kernel_ms is the HIP-event "
-                                 "duration inside the timed region, where calls_in_flight launches overlap; "
-                                 "algorithmic bytes = (|window| + 16) per read this kernel scored"},
-            "valu": {"gcups": cells / all_dp_s / 1e9, "cells_per_step": cells,
-                     "peak_int32_tops": VALU_PEAK_TOPS, "unit": "G cell updates/s"},
-            "device_ms_per_step": all_ms / a.steps, "isolated_call": {"k_dp_all_ms": iso_dp, "k_dp_band_ms": iso_band, "device_ms": iso_all},
-            "band_reads_per_step": acc["band"] / a.steps, "band_fallback_per_step": acc["band_fb"] / a.steps, "band": not a.no_band, "window_miss_reads_per_step": misses / a.steps,
-            "generic_kernel_items_per_step": fallback / a.steps,
-            "dedup_reads_per_step": acc["dedup"] / a.steps, "dedupe": not a.no_dedupe,
+            "loci_per_s": loci_all / elapsed,
+            "roofline": roof,
+            "valu": {"gcups": acc["cells"] / max(acc["dp_ms"] + acc["band_ms"], 1e-9) / 1e6, "cells_per_step": acc["cells"] / n,
+                     "unit": "G cell updates/s (cells the DP kernels executed / their summed HIP-event time)"},
+            "device_ms_per_step": acc["all_ms"] / n,
+            "band_reads_per_step": acc["band"] / n, "band_fallback_per_step": acc["band_fb"] / n, "band": not a.no_band,
+            "window_miss_reads_per_step": acc["misses"] / n, "generic_kernel_items_per_step": acc["fallback"] / n,
+            "dedup_reads_per_step": acc["dedup"] / n, "dedupe": not a.no_dedupe,
+            **extras,
             "parity_check": parity,
+            **({"strong_scaling_check": strong_check} if a.strong else {}),
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if use_dist:
-        j = (a.steps - 1) % G   # rank 0's block of the last collective, slot of the last step
-        if rank == 0 and not torch.equal(gathered[4 * j:4 * j + 4], out):
-            sys.exit("all_gather self-check failed")
+        if rank == 0 and not a.strong:   # rank 0's block of the last collective, slot of the last step
+            j = last % G
+            if not torch.equal(gathered[NF * j:NF * j + NF], out_last):
+                sys.exit("all_gather self-check failed")
         dist.destroy_process_group()
+    if rank == 0 and a.strong and strong_check != "identical":
+        sys.exit("strong-scaling table check failed")
     for c in ctxs:
         c.close()
 

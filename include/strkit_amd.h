@@ -112,7 +112,8 @@ typedef struct strk_stats {
     int32_t n_band_reads;  /* reads scored by the banded kernel ... */
     int32_t n_band_fallback; /* ... of which the certificate failed (re-scored by the exact kernels) */
     float band_kernel_ms;  /* HIP-event time of the banded kernel (k_dp_band) of this call */
-    int32_t reserved;
+    int32_t window_used;   /* half-width of the speculative candidate window this call ran with (params.window, or the
+                              level the library's default has adapted to) */
     int64_t band_bytes;    /* algorithmic bytes (|window| + 16 per read) of the reads k_plan routed to k_dp_band */
     int64_t exact_bytes;   /* ... and to the exact kernels (k_dp_all / k_dp_long / generic) */
 } strk_stats;
@@ -224,7 +225,10 @@ int64_t strk_bgzf_inflate(const uint8_t* comp, int64_t n_comp, uint8_t* out, int
  * starting at alt_start[i] instead of the record's own alignment (a realigned read); alt_* may be NULL.
  * status[i]: 0 = extracted, 1 = the read does not span both flanks (skipped), 2 = mean base quality of the tract below
  * min_avg_phred (skipped).  Extracted items append fl|tr|fr (flanks cut to flank_size, bases with PHRED <=
- * wildcard_threshold replaced by 'X') to seqs; seq_off is [n_items + 1]; nfl/ntr/nfr the three lengths. */
+ * wildcard_threshold replaced by 'X') to seqs; seq_off is [n_items + 1]; nfl/ntr/nfr the three lengths.
+ * seqs == NULL is a size query: status, the lengths and seq_off are filled (seq_off[n_items] = bytes needed), no bases are
+ * written.  A record that holds the long-CIGAR placeholder (<l_seq>S<ref_len>N) is read through its CG:B,I tag.  Items are
+ * processed by all host cores when there are more than a few hundred. */
 int strk_extract_reads(const uint8_t* buf, int64_t n_bytes, int32_t n_items, const int64_t* rec_off, const int64_t* coords,
                        const uint32_t* alt_cigar, const int64_t* alt_cigar_off, const int64_t* alt_start, int32_t flank_size,
                        int32_t min_avg_phred, int32_t wildcard_threshold, int32_t* status, int32_t* nfl, int32_t* ntr,

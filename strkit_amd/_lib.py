@@ -36,7 +36,7 @@ class StrkStats(C.Structure):
     _fields_ = [("dp_cells", C.c_int64), ("n_fallback", C.c_int32), ("n_miss_reads", C.c_int32),
                 ("n_miss_rounds", C.c_int32), ("kernel_ms", C.c_float), ("dp_kernel_ms", C.c_float),
                 ("n_dp_launches", C.c_int32), ("n_dedup_reads", C.c_int32), ("n_band_reads", C.c_int32),
-                ("n_band_fallback", C.c_int32), ("band_kernel_ms", C.c_float), ("reserved", C.c_int32),
+                ("n_band_fallback", C.c_int32), ("band_kernel_ms", C.c_float), ("window_used", C.c_int32),
                 ("band_bytes", C.c_int64), ("exact_bytes", C.c_int64)]
 
     def as_dict(self) -> dict:

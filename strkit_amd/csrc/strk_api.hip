@@ -344,6 +344,7 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
             stats->exact_bytes = (int64_t)u[3];
         }
         stats->n_dp_launches = 2;
+        stats->window_used = c->p_params.window;
         stats->n_fallback = c->h_counters[kCntClass0 + kGenericClass];
         stats->n_dedup_reads = c->h_counters[kCntDup];
         stats->n_band_reads = 0;
@@ -757,42 +758,73 @@ int strk_extract_reads(const uint8_t* buf, int64_t n_bytes, int32_t n_items, con
                        int32_t* nfr, uint8_t* seqs, int64_t seq_cap, int64_t* seq_off) {
     if (n_items < 0 || flank_size < 0) return fail(STRK_E_INVALID, "bad argument");
     if (n_items == 0) { if (seq_off) seq_off[0] = 0; return 0; }
-    if (!buf || !rec_off || !coords || !status || !nfl || !ntr || !nfr || !seqs || !seq_off) return fail(STRK_E_INVALID, "NULL argument");
+    if (!buf || !rec_off || !coords || !status || !nfl || !ntr || !nfr || !seq_off) return fail(STRK_E_INVALID, "NULL argument");
     static const char kBases[] = "=ACMGRSVTWYHKDBN";
-    strk_fe::Runs runs;
+    const int nt = n_items < 512 ? 1 : std::max(1, std::min<int>((int)std::thread::hardware_concurrency(), 32));
+    auto parallel = [&](auto&& body) {   // body(first item, last item): contiguous slices, one per thread
+        std::vector<std::thread> th;
+        const int32_t per = (n_items + nt - 1) / nt;
+        for (int t = 1; t < nt; ++t)
+            if (t * per < n_items) th.emplace_back(body, t * per, std::min(n_items, (t + 1) * per));
+        body(0, std::min(n_items, per));
+        for (auto& x : th) x.join();
+    };
+    // pass 1: where each read's flank | tract | flank lies (read positions a <= b <= c <= d), status, lengths
+    std::vector<int64_t> cut((size_t)n_items * 2);   // a and b; c = b + ntr, d = c + nfr
+    std::atomic<int> bad{-1};
+    parallel([&](int32_t i0, int32_t i1) {
+        strk_fe::Runs runs;
+        for (int32_t it = i0; it < i1; ++it) {
+            status[it] = 1; nfl[it] = ntr[it] = nfr[it] = 0;
+            strk_fe::Rec r;
+            int64_t next = 0;
+            if (!strk_fe::parse_rec(buf, n_bytes, rec_off[it], &r, &next)) { bad.store(it); return; }
+            const bool alt = alt_cigar && alt_cigar_off && alt_cigar_off[it + 1] > alt_cigar_off[it];
+            if (alt) runs.build(reinterpret_cast<const uint8_t*>(alt_cigar + alt_cigar_off[it]), (int32_t)(alt_cigar_off[it + 1] - alt_cigar_off[it]), alt_start ? alt_start[it] : 0);
+            else runs.build(r.cigar, r.n_cigar, r.pos);
+            int64_t q[4];
+            if (!strk_fe::read_coords(runs, coords[4 * (size_t)it], coords[4 * (size_t)it + 1], coords[4 * (size_t)it + 2], coords[4 * (size_t)it + 3], q)) continue;
+            const int64_t b = q[1], c = q[2];
+            const int64_t a = std::max(q[0], b - flank_size), d = std::min(q[3], c + flank_size);
+            if (a < 0 || d > r.l_seq || a > b || b > c || c > d) continue;   // coordinates outside the read: incomplete
+            const bool has_qual = !(r.l_seq > 0 && r.qual[0] == 0xFF);
+            if (has_qual && c > b) {   // LowMeanBaseQual on the tract bases (call_locus.py:1099-1115)
+                int64_t sum = 0;
+                for (int64_t i = b; i < c; ++i) sum += r.qual[i];
+                if ((double)sum / (double)(c - b) < (double)min_avg_phred) { status[it] = 2; continue; }
+            }
+            status[it] = 0;
+            nfl[it] = (int32_t)(b - a); ntr[it] = (int32_t)(c - b); nfr[it] = (int32_t)(d - c);
+            cut[2 * (size_t)it] = a;
+        }
+    });
+    if (bad.load() >= 0) return fail(STRK_E_INVALID, "item %d: malformed BAM record", bad.load());
     int64_t w = 0;
     seq_off[0] = 0;
     for (int32_t it = 0; it < n_items; ++it) {
-        status[it] = 1; nfl[it] = ntr[it] = nfr[it] = 0;
-        seq_off[it + 1] = w;
-        strk_fe::Rec r;
-        int64_t next = 0;
-        if (!strk_fe::parse_rec(buf, n_bytes, rec_off[it], &r, &next)) return fail(STRK_E_INVALID, "item %d: malformed BAM record", it);
-        const bool alt = alt_cigar && alt_cigar_off && alt_cigar_off[it + 1] > alt_cigar_off[it];
-        if (alt) runs.build(reinterpret_cast<const uint8_t*>(alt_cigar + alt_cigar_off[it]), (int32_t)(alt_cigar_off[it + 1] - alt_cigar_off[it]), alt_start ? alt_start[it] : 0);
-        else runs.build(r.cigar, r.n_cigar, r.pos);
-        int64_t q[4];
-        if (!strk_fe::read_coords(runs, coords[4 * (size_t)it], coords[4 * (size_t)it + 1], coords[4 * (size_t)it + 2], coords[4 * (size_t)it + 3], q)) continue;
-        const int64_t b = q[1], c = q[2];
-        const int64_t a = std::max(q[0], b - flank_size), d = std::min(q[3], c + flank_size);
-        if (a < 0 || d > r.l_seq || a > b || b > c || c > d) continue;   // coordinates outside the read: incomplete
-        const bool has_qual = !(r.l_seq > 0 && r.qual[0] == 0xFF);
-        if (has_qual && c > b) {   // LowMeanBaseQual on the tract bases (call_locus.py:1099-1115)
-            int64_t sum = 0;
-            for (int64_t i = b; i < c; ++i) sum += r.qual[i];
-            if ((double)sum / (double)(c - b) < (double)min_avg_phred) { status[it] = 2; continue; }
-        }
-        if (w + (d - a) > seq_cap) return fail(STRK_E_NOMEM, "sequence buffer too small");
-        for (int64_t i = a; i < d; ++i) {
-            const uint8_t byte = r.seq[i >> 1];
-            char ch = kBases[(i & 1) ? (byte & 15) : (byte >> 4)];
-            if (has_qual && (int32_t)r.qual[i] <= wildcard_threshold) ch = 'X';   // call_locus.py:79,1101-1106
-            seqs[w++] = (uint8_t)ch;
-        }
-        status[it] = 0;
-        nfl[it] = (int32_t)(b - a); ntr[it] = (int32_t)(c - b); nfr[it] = (int32_t)(d - c);
+        w += (int64_t)nfl[it] + ntr[it] + nfr[it];
         seq_off[it + 1] = w;
     }
+    if (!seqs) return 0;   // size query: seq_off[n_items] bytes are needed
+    if (w > seq_cap) return fail(STRK_E_NOMEM, "sequence buffer too small (%lld < %lld)", (long long)seq_cap, (long long)w);
+    // pass 2: bases (4 bit -> ASCII), low-quality bases -> 'X' (call_locus.py:79,1101-1106)
+    parallel([&](int32_t i0, int32_t i1) {
+        for (int32_t it = i0; it < i1; ++it) {
+            if (status[it] != 0) continue;
+            strk_fe::Rec r;
+            int64_t next = 0;
+            (void)strk_fe::parse_rec(buf, n_bytes, rec_off[it], &r, &next);
+            const bool has_qual = !(r.l_seq > 0 && r.qual[0] == 0xFF);
+            const int64_t a = cut[2 * (size_t)it], d = a + nfl[it] + ntr[it] + nfr[it];
+            uint8_t* o = seqs + seq_off[it];
+            for (int64_t i = a; i < d; ++i) {
+                const uint8_t byte = r.seq[i >> 1];
+                char ch = kBases[(i & 1) ? (byte & 15) : (byte >> 4)];
+                if (has_qual && (int32_t)r.qual[i] <= wildcard_threshold) ch = 'X';
+                *o++ = (uint8_t)ch;
+            }
+        }
+    });
     return 0;
 }
 

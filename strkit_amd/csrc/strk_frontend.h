@@ -27,7 +27,7 @@ constexpr bool is_aligned(uint32_t op) { return op == 0 || op == 7 || op == 8; }
 // Fixed part of a BAM alignment record (after block_size): refID, pos, l_read_name, mapq, bin, n_cigar_op, flag,
 // l_seq, next_refID, next_pos, tlen = 32 bytes, then read_name, cigar, seq (4 bit), qual.
 struct Rec {
-    int32_t tid, pos, l_name, n_cigar, flag, l_seq;
+    int32_t tid, pos, l_name, n_cigar, flag, l_seq;   // n_cigar / cigar: the real CIGAR (from the CG tag when the record holds the long-CIGAR placeholder)
     const uint8_t* name;
     const uint8_t* cigar;
     const uint8_t* seq;
@@ -51,6 +51,41 @@ inline bool parse_rec(const uint8_t* buf, int64_t n_bytes, int64_t off, Rec* r, 
     r->seq = r->cigar + 4 * (size_t)r->n_cigar;
     r->qual = r->seq + (r->l_seq + 1) / 2;
     *next = off + 4 + block;
+    // Alignments with more than 65 535 CIGAR operations (ultralong reads) store the placeholder <l_seq>S<ref_len>N
+    // and the real CIGAR in the tag CG:B,I (SAM specification, section 4.2.2).
+    if (r->n_cigar == 2 && r->l_seq > 0) {
+        const uint32_t c0 = rd_u32(r->cigar), c1 = rd_u32(r->cigar + 4);
+        if ((c0 & 15u) == 4 && (int64_t)(c0 >> 4) == r->l_seq && (c1 & 15u) == 3) {
+            const uint8_t* t = r->qual + r->l_seq;
+            const uint8_t* const tend = p + block;
+            while (t + 3 <= tend) {
+                const char ty = (char)t[2];
+                const uint8_t* v = t + 3;
+                int64_t sz = -1;
+                if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+                else if (ty == 's' || ty == 'S') sz = 2;
+                else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+                else if (ty == 'Z' || ty == 'H') {
+                    const void* z = memchr(v, 0, (size_t)(tend - v));
+                    if (!z) return false;
+                    sz = (const uint8_t*)z - v + 1;
+                } else if (ty == 'B') {
+                    if (v + 5 > tend) return false;
+                    const char sub = (char)v[0];
+                    const int64_t cnt = rd_u32(v + 1);
+                    const int64_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
+                    sz = 5 + cnt * es;
+                    if (t[0] == 'C' && t[1] == 'G' && sub == 'I' && v + sz <= tend) {
+                        r->cigar = v + 5;
+                        r->n_cigar = (int32_t)cnt;
+                        break;
+                    }
+                }
+                if (sz < 0 || v + sz > tend) return false;
+                t = v + sz;
+            }
+        }
+    }
     return true;
 }
 
@@ -98,7 +133,9 @@ struct Runs {
 inline bool read_coords(const Runs& ix, int64_t lfc, int64_t lc, int64_t rc, int64_t rfc, int64_t out[4]) {
     const int64_t n = ix.n_pairs;
     if (n == 0) return false;
-    const bool full_l = ix.r0.front() <= lfc, full_r = ix.r0.back() + ix.ln.back() - 1 >= rfc - 1;
+    // call_locus.py:907-909 skips a read when left_flank_coord < segment.start or right_flank_coord >= segment.end:
+    // the last aligned reference base (end - 1) must be at or right of right_flank_coord
+    const bool full_l = ix.r0.front() <= lfc, full_r = ix.r0.back() + ix.ln.back() - 1 >= rfc;
     if (!(full_l && full_r)) return false;
     const int64_t i_lfs = ix.first_pair_at_or_after(lfc), i_l = ix.first_pair_at_or_after(lc);
     const int64_t i_r = ix.first_pair_at_or_after(rc), i_rfe = ix.first_pair_at_or_after(rfc);

@@ -14,7 +14,9 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-__all__ = ["AlignedSegment", "BamFile", "read_bam", "write_bam", "CIGAR_OPS"]
+from .loci import resolve_contig
+
+__all__ = ["AlignedSegment", "BamFile", "read_bam", "write_bam", "real_cigar", "CIGAR_OPS"]
 
 CIGAR_OPS = "MIDNSHP=X"
 _SEQ_CODES = "=ACMGRSVTWYHKDBN"
@@ -88,11 +90,38 @@ class BamFile:
 
     def fetch(self, contig: str, start: int, end: int) -> list[AlignedSegment]:
         """Mapped segments that overlap [start, end), in coordinate order."""
-        if contig not in self._by_contig:
+        contig = resolve_contig(self._by_contig, contig)
+        if contig is None:
             return []
         starts, ends, segs = self._by_contig[contig]
         hi = int(np.searchsorted(starts, end, side="left"))
         return [segs[i] for i in np.nonzero(ends[:hi] > start)[0]]
+
+
+def real_cigar(cigar: np.ndarray, l_seq: int, tags: bytes) -> np.ndarray:
+    """Alignments with more than 65 535 CIGAR operations store the placeholder ``<l_seq>S<ref_len>N`` in the fixed
+    field and the real CIGAR in the tag ``CG:B,I`` (SAM specification §4.2.2); everything downstream sees the real one."""
+    if not (cigar.size == 2 and l_seq > 0 and int(cigar[0]) & 15 == 4 and int(cigar[0]) >> 4 == l_seq and int(cigar[1]) & 15 == 3):
+        return cigar
+    t, n = 0, len(tags)
+    fixed = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}
+    while t + 3 <= n:
+        tag, ty = tags[t:t + 2], chr(tags[t + 2])
+        v = t + 3
+        if ty in fixed:
+            size = fixed[ty]
+        elif ty in "ZH":
+            size = tags.index(b"\0", v) - v + 1
+        elif ty == "B":
+            sub = chr(tags[v])
+            cnt, = struct.unpack_from("<I", tags, v + 1)
+            size = 5 + cnt * {"c": 1, "C": 1, "s": 2, "S": 2}.get(sub, 4)
+            if tag == b"CG" and sub == "I":
+                return np.frombuffer(tags, np.uint32, cnt, v + 5).copy()
+        else:
+            break
+        t = v + size
+    return cigar
 
 
 def _decode_seq(packed: np.ndarray, l_seq: int) -> str:
@@ -133,8 +162,9 @@ def read_bam(path: str) -> BamFile:
         p += (l_seq + 1) // 2
         qual = np.frombuffer(data, np.uint8, l_seq, p).copy()
         p += l_seq
-        segs.append(AlignedSegment(name, flag, contigs[ref_id][0] if ref_id >= 0 else "*", pos, mapq, cigar, seq,
-                                   None if l_seq and qual[0] == 0xFF else qual, data[p:rec + block_size]))
+        tags = data[p:rec + block_size]
+        segs.append(AlignedSegment(name, flag, contigs[ref_id][0] if ref_id >= 0 else "*", pos, mapq,
+                                   real_cigar(cigar, l_seq, tags), seq, None if l_seq and qual[0] == 0xFF else qual, tags))
         off = rec + block_size
     return BamFile(contigs, segs, text)
 
@@ -174,6 +204,10 @@ def write_bam(path: str, contigs: list[tuple[str, int]], records: list[dict]) ->
     for r in records:
         cig = np.array([(ln << 4) | CIGAR_OPS.index(op) for ln, op in r["cigar"]], np.uint32)
         seq = r["seq"]
+        if len(cig) > 65535 or r.get("long_cigar"):   # SAM §4.2.2: placeholder in the fixed field, real CIGAR in CG:B,I
+            ref_len0 = sum(ln for ln, op in r["cigar"] if op in "MDN=X")
+            r = dict(r, tags=r.get("tags", b"") + b"CGBI" + struct.pack("<I", len(cig)) + cig.tobytes())
+            cig = np.array([(len(seq) << 4) | 4, (ref_len0 << 4) | 3], np.uint32)
         nib = lut[np.frombuffer(seq.encode("ascii"), np.uint8)]
         if len(seq) & 1:
             nib = np.concatenate((nib, np.zeros(1, np.uint8)))
@@ -184,7 +218,7 @@ def write_bam(path: str, contigs: list[tuple[str, int]], records: list[dict]) ->
         name = r["name"].encode() + b"\0"
         body = struct.pack("<iiBBHHHIiii", tid[r["contig"]], r["pos"], len(name), r.get("mapq", 60),
                            _reg2bin(r["pos"], r["pos"] + max(ref_len, 1)), len(cig), r.get("flag", 0), len(seq), -1, -1, 0)
-        body += name + cig.tobytes() + packed.tobytes() + qb
+        body += name + cig.tobytes() + packed.tobytes() + qb + r.get("tags", b"")
         buf += struct.pack("<i", len(body)) + body
     with open(path, "wb") as fh:
         fh.write(_bgzf_blocks(bytes(buf)))

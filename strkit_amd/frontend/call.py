@@ -8,7 +8,9 @@ boundaries), :837-958 (read coordinates, optional realignment), :1082-1161 (trip
 from __future__ import annotations
 
 import json
+import sys
 import time
+from dataclasses import dataclass
 
 import numpy as np
 
@@ -23,13 +25,28 @@ from .bam import BamFile, read_bam
 from .extract import (LowMeanBaseQual, MIN_AVG_PHRED, get_read_coords_from_cigar, get_read_coords_from_matched_pairs,
                       get_sequence_data_for_locus)
 from .fasta import Fasta
-from .loci import Locus, load_loci
+from .loci import Locus, load_loci, parse_loci_bed, resolve_contig
 from .native import NativeBam, extract_reads, realign_cigar_to_read_alignment
 
-__all__ = ["call_sample", "call_locus", "call_blocks", "call_blocks_sharded", "deal_locus_blocks", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
+__all__ = ["CallOptions", "call_sample", "call_locus", "call_blocks", "call_blocks_sharded", "deal_locus_blocks", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
+
+@dataclass
+class CallOptions:
+    """The knobs of `strkit call` this path honours (strkit/call/params.py:20-50) plus the two semantic switches of the
+    read-side counter that the reference's tree does not pin: tools/compare_strkit_json.py sweeps them."""
+    flank_size: int = 70
+    realign: bool = False
+    min_avg_phred: int = MIN_AVG_PHRED
+    max_reads: int = 250
+    respect_ref: bool = False
+    rc_params: RepeatCountParams | None = None
+    min_read_align_score: float = MIN_READ_ALIGN_SCORE
+    tie_rule: int = _lib.STRK_TIE_FIRST
+    end_flags: int = _lib.STRK_SG_ALL
+
 
 MAX_READS = 250                 # params.max_reads default (strkit/call/params.py:21)
-DEFAULT_REF_MAX_ITERS = 100     # call_locus.py: default_ref_max_iters
+DEFAULT_REF_MAX_ITERS = 250     # call_locus.py:71 default_ref_max_iters (100 there is only the "slow" warning level, :72)
 VCF_ANCHOR_SIZE = 5             # params.vcf_anchor_size default
 
 
@@ -96,39 +113,52 @@ def _locus_dict(locus: Locus) -> dict:
 def call_locus(locus: Locus, bam: BamFile, ref: Fasta, flank_size: int = 70, realign: bool = False,
                min_avg_phred: int = MIN_AVG_PHRED, max_reads: int = MAX_READS, respect_ref: bool = False,
                rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE,
-               ctx: _lib.Context | None = None) -> dict:
+               ctx: _lib.Context | None = None, tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL) -> dict:
     """The per-locus entry point (strkit/call/call_locus.py:974-995) over this backend: one locus, its LocusResult
     record up to the read records (a block of one through the same path as call_sample)."""
-    return call_blocks([[locus]], bam, ref, flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params,
-                       min_read_align_score, ctx)[0][0]
+    opts = CallOptions(flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params, min_read_align_score, tie_rule, end_flags)
+    return call_blocks([[locus]], bam, ref, opts, ctx)[0][0]
 
 
 def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size: int = 70, realign: bool = False,
                 min_avg_phred: int = MIN_AVG_PHRED, max_reads: int = MAX_READS, respect_ref: bool = False,
                 sample_id: str | None = None, ctx: _lib.Context | None = None, processes: int = 1,
-                rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE) -> dict:
+                rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE,
+                tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL) -> dict:
     bam = NativeBam(bam) if isinstance(bam, str) else bam      # a path: records stay in the decompressed stream
     ref = Fasta(ref) if isinstance(ref, str) else ref
     t0 = time.perf_counter()
-    blocks = load_loci(loci_file, flank_size, contigs=set(bam.references) & set(ref.references), processes=processes)
+    opts = CallOptions(flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params, min_read_align_score, tie_rule, end_flags)
+    # catalog, alignment file and reference may or may not carry the "chr" prefix (call_locus.py:758 normalize_contig):
+    # a locus is called when its contig exists, under either spelling, in both files
+    both = {c for c in bam.references if resolve_contig(ref.references, c) is not None}
+    blocks = load_loci(loci_file, flank_size, contigs=both, processes=processes)
+    n_catalog = sum(1 for _ in parse_loci_bed(loci_file))
+    n_loaded = sum(len(b) for b in blocks)
+    if n_loaded < n_catalog:
+        print(f"strkit_amd: {n_catalog - n_loaded} of {n_catalog} catalog loci lie on contigs that the alignment file or "
+              f"the reference does not have; they are not called", file=sys.stderr)
 
     def run(bl):
-        return call_blocks(bl, bam, ref, flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params,
-                           min_read_align_score, ctx)
+        return call_blocks(bl, bam, ref, opts, ctx)
 
     if _distributed():          # launched under torch.distributed (one rank per GPU): shard the blocks
         results, n_depth, tm = call_blocks_sharded(blocks, run)
     else:
         results, n_depth, tm = run(blocks)
+    errors = tm.pop("errors", [])
     # same top-level layout as the reference's report (strkit/call/output/json_report.py:37-60,127-154)
     return {"sample_id": sample_id,
             "caller": {"name": "strkit_amd", "version": _lib.load().strk_version().decode()},
             "parameters": {"flank_size": flank_size, "realign": realign, "min_avg_phred": min_avg_phred,
                            "max_reads": max_reads, "respect_ref": respect_ref, "rc_method": "repalign",
-                           "min_read_align_score": min_read_align_score, "processes": processes},
+                           "min_read_align_score": min_read_align_score, "processes": processes,
+                           **({"tie_rule": tie_rule} if tie_rule != _lib.STRK_TIE_FIRST else {}),
+                           **({"end_flags": end_flags} if end_flags != _lib.STRK_SG_ALL else {})},
             "contigs": sorted({r["contig"] for r in results}),
-            "catalog": {"num_loci": len(results)},
+            "catalog": {"num_loci": len(results), "num_loci_unknown_contig": n_catalog - n_loaded},
             "results": results,
+            "errors": errors,
             "avg_read_depth": n_depth / max(1, sum(1 for r in results if "reads" in r)),
             "runtime": time.perf_counter() - t0, "stage_times": {k: round(v, 4) for k, v in tm.items()}}
 
@@ -158,206 +188,234 @@ def call_blocks_sharded(blocks, call_fn) -> tuple[list[dict], int, dict]:
     gathered: list = [None] * world
     dist.all_gather_object(gathered, (results, n_depth, tm))
     merged = sorted((r for part, _, _ in gathered for r in part), key=lambda r: r["locus_index"])
-    stage = {}
+    stage = {"errors": sorted((e for _, _, t in gathered for e in t.get("errors", [])), key=lambda e: e["locus_index"])}
     for _, _, t in gathered:
         for k, v in t.items():
-            stage[k] = max(stage.get(k, 0.0), v)        # ranks run side by side: the slowest one counts
+            if k != "errors":
+                stage[k] = max(stage.get(k, 0.0), v)    # ranks run side by side: the slowest one counts
     return merged, sum(n for _, n, _ in gathered), stage
 
 
-def call_blocks(blocks, bam: BamFile, ref: Fasta, flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params,
-                min_read_align_score, ctx):
+def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = None, ctx=None):
     """Worker loop over blocks of loci (strkit/call/call_sample.py:103-197): (results in locus order, reads kept,
-    stage times)."""
+    stage times).  An error of the library inside a block is handled the way the reference's worker handles any
+    exception of call_locus (call_sample.py:159-166: logged, the locus is dropped, the run goes on): the block is
+    re-run locus by locus so that only the locus that fails is lost; `stage times["errors"]` lists them."""
+    opts = opts or CallOptions()
     ctx = ctx or _lib.default_context()
-    if isinstance(bam, NativeBam):
-        return _call_blocks_native(blocks, bam, ref, flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params,
-                                   min_read_align_score, ctx)
+    run_block = _call_block_native if isinstance(bam, NativeBam) else _call_block_python
     results: list[dict] = []
     n_depth = 0
-    tm = {"ref_side_s": 0.0, "realign_s": 0.0, "extract_s": 0.0, "count_s": 0.0}
+    tm = {"ref_side_s": 0.0, "realign_s": 0.0, "extract_s": 0.0, "count_s": 0.0, "errors": []}
+
+    def safe(block):
+        nonlocal n_depth
+        try:
+            rows, n = run_block(block, bam, ref, opts, ctx, tm)
+        except _lib.StrkError as e:
+            if len(block) > 1:
+                for locus in block:
+                    safe([locus])
+                return
+            print(f"strkit_amd: {block[0].log_str()} - skipping locus: {e}", file=sys.stderr)
+            tm["errors"].append({"locus_index": block[0].t_idx, "error": str(e)})
+            return
+        results.extend(rows)
+        n_depth += n
 
     for block in blocks:
-        prepared = []                     # (locus, ref data, [(segment, query_coords, ref_coords) ...])
-        realign_jobs = []                 # (index into prepared, index of the segment)
-        t_a = time.perf_counter()
-        ref_data = get_loci_with_ref_data(block, ref, respect_ref, ctx)
-        tm["ref_side_s"] += time.perf_counter() - t_a
-        for locus, rd in zip(block, ref_data):
-            if rd is None:
-                results.append(_locus_dict(locus))    # SkipLocus: locus fields + empty call (call_locus.py:1032-1036)
+        safe(block)
+    results.sort(key=lambda r: r["locus_index"])
+    return results, n_depth, tm
+
+
+def _empty_counts(n_loci):
+    return ({k: np.zeros(0, np.int32) for k in ("cn", "score", "n_iters", "start")},
+            {"sc": np.zeros(0), "keep": np.zeros(0, bool), "locus_ok": np.ones(n_loci, bool)})
+
+
+def _count(batch: LocusBatch, opts: CallOptions, ctx):
+    if not batch.n_reads:
+        return _empty_counts(batch.n_loci)
+    res = count_loci(batch, opts.rc_params, ctx=ctx, tie_rule=opts.tie_rule, end_flags=opts.end_flags)
+    return res, filter_reads(batch, res, opts.min_read_align_score)
+
+
+def _locus_row(locus: Locus, rd: dict, reads: dict, opts: CallOptions) -> dict:
+    row = _locus_dict(locus)
+    row["ref_cn"] = int(rd["ref_cn"])
+    if not opts.respect_ref:
+        row["start_adj"], row["end_adj"] = rd["left_coord_adj"], rd["right_coord_adj"]
+    row["ref_start_anchor"] = rd["ref_left_flank_seq"][-VCF_ANCHOR_SIZE:].upper()      # call_locus.py:1350
+    row["ref_seq"] = rd["ref_seq"]                                                      # call_locus.py:1351 (case kept)
+    # allele calling is not part of this backend: the record stops where call_locus.py:1300 starts
+    row["peaks"], row["read_peaks_called"] = None, False
+    row["reads"] = reads
+    return row
+
+
+def _call_block_python(block, bam: BamFile, ref: Fasta, opts: CallOptions, ctx, tm):
+    """One block through bam.py / extract.py (the readable statement of the front end): (rows, reads kept)."""
+    flank_size = opts.flank_size
+    results: list[dict] = []
+    n_depth = 0
+    prepared = []                     # (locus, ref data, [(segment, query_coords, ref_coords) ...])
+    realign_jobs = []                 # (index into prepared, index of the segment)
+    t_a = time.perf_counter()
+    ref_data = get_loci_with_ref_data(block, ref, opts.respect_ref, ctx)
+    tm["ref_side_s"] += time.perf_counter() - t_a
+    for locus, rd in zip(block, ref_data):
+        if rd is None:
+            results.append(_locus_dict(locus))    # SkipLocus: locus fields + empty call (call_locus.py:1032-1036)
+            continue
+        segs = bam.fetch(locus.contig, locus.left_flank_coord, locus.right_flank_coord)[:opts.max_reads]
+        entries = []
+        for seg in segs:
+            if opts.realign and seg.soft_clip_overlaps_locus(locus):
+                realign_jobs.append((len(prepared), len(entries)))
+            entries.append([seg, None, False])
+        prepared.append((locus, rd, entries))
+    t_a = time.perf_counter()
+    if realign_jobs:                  # every soft-clipped read of the block in one device call (realign.py:75-154)
+        refs_, reads_, lfcs = [], [], []
+        for pi, ei in realign_jobs:
+            locus, rd, entries = prepared[pi]
+            seg = entries[ei][0]
+            refs_.append(rd["ref_total_seq"])
+            reads_.append(calculate_seq_with_wildcards(seg.query_sequence, seg.query_qualities, 3))
+            lfcs.append(locus.left_flank_coord)
+        for (pi, ei), ac in zip(realign_jobs, realign_reads(refs_, reads_, lfcs, flank_size, context=ctx)):
+            if ac is not None:
+                prepared[pi][2][ei][1] = (ac.query_coords, ac.ref_coords)
+                prepared[pi][2][ei][2] = True
+    tm["realign_s"] += time.perf_counter() - t_a
+    t_a = time.perf_counter()
+    # triples of every read of the block -> one batched device call
+    loci_reads, meta = [], []
+    for locus, rd, entries in prepared:
+        triples, names = [], []
+        for seg, pairs, realigned in entries:
+            if pairs is not None:     # realigned: the pairs of the new alignment
+                coords = get_read_coords_from_matched_pairs(locus.left_flank_coord, rd["left_coord_adj"],
+                                                            rd["right_coord_adj"], locus.right_flank_coord, *pairs)
+            else:
+                coords = get_read_coords_from_cigar(locus.left_flank_coord, rd["left_coord_adj"],
+                                                    rd["right_coord_adj"], locus.right_flank_coord, seg)
+            if coords.is_incomplete():
                 continue
-            segs = bam.fetch(locus.contig, locus.left_flank_coord, locus.right_flank_coord)[:max_reads]
-            entries = []
-            for seg in segs:
-                if realign and seg.soft_clip_overlaps_locus(locus):
-                    realign_jobs.append((len(prepared), len(entries)))
-                entries.append([seg, None, False])
-            prepared.append((locus, rd, entries))
+            try:
+                sd = get_sequence_data_for_locus(seg, coords, flank_size, opts.min_avg_phred)
+            except LowMeanBaseQual:
+                continue
+            triples.append((sd.flank_left_seq_wc[-flank_size:], sd.tr_seq_wc, sd.flank_right_seq_wc[:flank_size]))
+            names.append((seg.name, seg.strand, realigned, len(sd.tr_seq)))
+        loci_reads.append((locus.motif, triples))
+        meta.append(names)
+    if not prepared:
+        return results, 0
+    batch = LocusBatch.from_reads(loci_reads)
+    tm["extract_s"] += time.perf_counter() - t_a
+    t_a = time.perf_counter()
+    res, flt = _count(batch, opts, ctx)
+    tm["count_s"] += time.perf_counter() - t_a
+    for li, (locus, rd, _) in enumerate(prepared):
+        r0, r1 = int(batch.read_off[li]), int(batch.read_off[li + 1])
+        kept = [r for r in range(r0, r1) if flt["keep"][r]]
+        reads = {}
+        for r in kept:
+            name, strand, realigned, sl = meta[li][r - r0]
+            sc = float(flt["sc"][r])
+            reads[name] = {"s": strand, "cn": int(res["cn"][r]), "w": 1.0 / len(kept),
+                           "sc": None if np.isnan(sc) else sc, "sl": sl, **({"realn": True} if realigned else {})}
+        row = _locus_row(locus, rd, reads if flt["locus_ok"][li] else {}, opts)
+        n_depth += len(row["reads"])
+        results.append(row)
+    return results, n_depth
+
+
+def _call_block_native(block, bam, ref: Fasta, opts: CallOptions, ctx, tm):
+    """One block over a NativeBam: ONE strk_extract_reads call cuts every read of every locus; Python only loops over
+    loci (fetch by numpy) and over the reads that end up in the report.  (rows, reads kept)"""
+    flank_size = opts.flank_size
+    results: list[dict] = []
+    n_depth = 0
+    t_a = time.perf_counter()
+    ref_data = get_loci_with_ref_data(block, ref, opts.respect_ref, ctx)
+    tm["ref_side_s"] += time.perf_counter() - t_a
+    t_a = time.perf_counter()
+    live, rec_parts, coord_parts, counts = [], [], [], []
+    for locus, rd in zip(block, ref_data):
+        if rd is None:
+            results.append(_locus_dict(locus))
+            continue
+        idx = bam.fetch_indices(locus.contig, locus.left_flank_coord, locus.right_flank_coord)[:opts.max_reads]
+        live.append((locus, rd))
+        rec_parts.append(idx)
+        coord_parts.append(np.tile(np.array([locus.left_flank_coord, rd["left_coord_adj"], rd["right_coord_adj"],
+                                             locus.right_flank_coord], np.int64), (len(idx), 1)))
+        counts.append(len(idx))
+    if not live:
+        return results, 0
+    rec = np.concatenate(rec_parts) if rec_parts else np.zeros(0, np.int64)
+    coords = np.concatenate(coord_parts) if coord_parts else np.zeros((0, 4), np.int64)
+    item_locus = np.repeat(np.arange(len(live)), counts)
+    tm["extract_s"] += time.perf_counter() - t_a
+    alt = None
+    if opts.realign and rec.size:     # soft-clipped reads of the whole block in one device call (realign.py:75-154)
         t_a = time.perf_counter()
-        if realign_jobs:                  # every soft-clipped read of the block in one device call (realign.py:75-154)
-            refs_, reads_, lfcs = [], [], []
-            for pi, ei in realign_jobs:
-                locus, rd, entries = prepared[pi]
-                seg = entries[ei][0]
-                refs_.append(rd["ref_total_seq"])
+        lf = np.array([l.left_flank_coord for l, _ in live], np.int64)[item_locus]
+        rf = np.array([l.right_flank_coord for l, _ in live], np.int64)[item_locus]
+        left = (bam.clip_l[rec] > 0) & (bam.pos[rec] >= lf) & (bam.pos[rec] <= rf)
+        right = (bam.clip_r[rec] > 0) & (bam.end[rec] >= lf) & (bam.end[rec] <= rf)
+        cand = np.nonzero(left | right)[0]
+        if cand.size:
+            refs_, reads_ = [], []
+            for it in cand:
+                seg = bam.segment(int(rec[it]))
+                refs_.append(live[int(item_locus[it])][1]["ref_total_seq"])
                 reads_.append(calculate_seq_with_wildcards(seg.query_sequence, seg.query_qualities, 3))
-                lfcs.append(locus.left_flank_coord)
-            for (pi, ei), ac in zip(realign_jobs, realign_reads(refs_, reads_, lfcs, flank_size, context=ctx)):
-                if ac is not None:
-                    prepared[pi][2][ei][1] = (ac.query_coords, ac.ref_coords)
-                    prepared[pi][2][ei][2] = True
+            gate = realign_gate(flank_size)
+            alt = {}
+            for it, (sc, _e, cg) in zip(cand, realign_pairs(refs_, reads_, context=ctx)):
+                if sc >= gate:
+                    alt[int(it)] = (realign_cigar_to_read_alignment(cg), int(lf[it]))
         tm["realign_s"] += time.perf_counter() - t_a
-        t_a = time.perf_counter()
-        # triples of every read of the block -> one batched device call
-        loci_reads, meta = [], []
-        for locus, rd, entries in prepared:
-            triples, names = [], []
-            for seg, pairs, realigned in entries:
-                if pairs is not None:     # realigned: the pairs of the new alignment
-                    coords = get_read_coords_from_matched_pairs(locus.left_flank_coord, rd["left_coord_adj"],
-                                                                rd["right_coord_adj"], locus.right_flank_coord, *pairs)
-                else:
-                    coords = get_read_coords_from_cigar(locus.left_flank_coord, rd["left_coord_adj"],
-                                                        rd["right_coord_adj"], locus.right_flank_coord, seg)
-                if coords.is_incomplete():
-                    continue
-                try:
-                    sd = get_sequence_data_for_locus(seg, coords, flank_size, min_avg_phred)
-                except LowMeanBaseQual:
-                    continue
-                triples.append((sd.flank_left_seq_wc[-flank_size:], sd.tr_seq_wc, sd.flank_right_seq_wc[:flank_size]))
-                names.append((seg.name, seg.strand, realigned, len(sd.tr_seq)))
-            loci_reads.append((locus.motif, triples))
-            meta.append(names)
-        if not prepared:
-            continue
-        batch = LocusBatch.from_reads(loci_reads)
-        tm["extract_s"] += time.perf_counter() - t_a
-        t_a = time.perf_counter()
-        res = count_loci(batch, rc_params, ctx=ctx) if batch.n_reads else {k: np.zeros(0, np.int32) for k in ("cn", "score", "n_iters", "start")}
-        flt = filter_reads(batch, res, min_read_align_score) if batch.n_reads else {"sc": np.zeros(0), "keep": np.zeros(0, bool), "locus_ok": np.ones(batch.n_loci, bool)}
-        tm["count_s"] += time.perf_counter() - t_a
-        for li, (locus, rd, _) in enumerate(prepared):
-            r0, r1 = int(batch.read_off[li]), int(batch.read_off[li + 1])
-            kept = [r for r in range(r0, r1) if flt["keep"][r]]
-            reads = {}
-            for r in kept:
-                name, strand, realigned, sl = meta[li][r - r0]
-                sc = float(flt["sc"][r])
-                reads[name] = {"s": strand, "cn": int(res["cn"][r]), "w": 1.0 / len(kept),
-                               "sc": None if np.isnan(sc) else sc, "sl": sl, **({"realn": True} if realigned else {})}
-            row = _locus_dict(locus)
-            row["ref_cn"] = int(rd["ref_cn"])
-            if not respect_ref:
-                row["start_adj"], row["end_adj"] = rd["left_coord_adj"], rd["right_coord_adj"]
-            row["ref_start_anchor"] = rd["ref_left_flank_seq"][-VCF_ANCHOR_SIZE:].upper()
-            # allele calling is not part of this backend: the record stops where call_locus.py:1300 starts
-            row["peaks"], row["read_peaks_called"] = None, False
-            row["reads"] = reads if flt["locus_ok"][li] else {}
-            n_depth += len(row["reads"])
-            results.append(row)
-    results.sort(key=lambda r: r["locus_index"])
-    return results, n_depth, tm
-
-
-def _call_blocks_native(blocks, bam, ref: Fasta, flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params,
-                        min_read_align_score, ctx):
-    """call_blocks over a NativeBam: per block ONE strk_extract_reads call cuts every read of every locus; Python only
-    loops over loci (fetch by numpy) and over the reads that end up in the report."""
-    results: list[dict] = []
-    n_depth = 0
-    tm = {"ref_side_s": 0.0, "realign_s": 0.0, "extract_s": 0.0, "count_s": 0.0}
-    for block in blocks:
-        t_a = time.perf_counter()
-        ref_data = get_loci_with_ref_data(block, ref, respect_ref, ctx)
-        tm["ref_side_s"] += time.perf_counter() - t_a
-        t_a = time.perf_counter()
-        live, rec_parts, coord_parts, counts = [], [], [], []
-        for locus, rd in zip(block, ref_data):
-            if rd is None:
-                results.append(_locus_dict(locus))
-                continue
-            idx = bam.fetch_indices(locus.contig, locus.left_flank_coord, locus.right_flank_coord)[:max_reads]
-            live.append((locus, rd))
-            rec_parts.append(idx)
-            coord_parts.append(np.tile(np.array([locus.left_flank_coord, rd["left_coord_adj"], rd["right_coord_adj"],
-                                                 locus.right_flank_coord], np.int64), (len(idx), 1)))
-            counts.append(len(idx))
-        if not live:
-            continue
-        rec = np.concatenate(rec_parts) if rec_parts else np.zeros(0, np.int64)
-        coords = np.concatenate(coord_parts) if coord_parts else np.zeros((0, 4), np.int64)
-        item_locus = np.repeat(np.arange(len(live)), counts)
-        tm["extract_s"] += time.perf_counter() - t_a
-        alt = None
-        if realign and rec.size:          # soft-clipped reads of the whole block in one device call (realign.py:75-154)
-            t_a = time.perf_counter()
-            lf = np.array([l.left_flank_coord for l, _ in live], np.int64)[item_locus]
-            rf = np.array([l.right_flank_coord for l, _ in live], np.int64)[item_locus]
-            left = (bam.clip_l[rec] > 0) & (bam.pos[rec] >= lf) & (bam.pos[rec] <= rf)
-            right = (bam.clip_r[rec] > 0) & (bam.end[rec] >= lf) & (bam.end[rec] <= rf)
-            cand = np.nonzero(left | right)[0]
-            if cand.size:
-                refs_, reads_ = [], []
-                for it in cand:
-                    seg = bam.segment(int(rec[it]))
-                    refs_.append(live[int(item_locus[it])][1]["ref_total_seq"])
-                    reads_.append(calculate_seq_with_wildcards(seg.query_sequence, seg.query_qualities, 3))
-                gate = realign_gate(flank_size)
-                alt = {}
-                for it, (sc, _e, cg) in zip(cand, realign_pairs(refs_, reads_, context=ctx)):
-                    if sc >= gate:
-                        alt[int(it)] = (realign_cigar_to_read_alignment(cg), int(lf[it]))
-            tm["realign_s"] += time.perf_counter() - t_a
-        t_a = time.perf_counter()
-        ex = extract_reads(bam, rec, coords, flank_size, min_avg_phred, 3, alt)
-        ok = ex["status"] == 0
-        n_ok_per_locus = np.bincount(item_locus[ok], minlength=len(live))
-        motifs = [l.motif.encode() for l, _ in live]
-        m_per_item = np.array([len(m) for m in motifs], np.int64)[item_locus[ok]]
-        ntr_ok = ex["ntr"][ok]
-        batch = LocusBatch(
-            seqs=ex["seqs"], seq_off=np.concatenate(([0], ex["seq_off"][1:][ok])).astype(np.int64),
-            nfl=ex["nfl"][ok], ntr=ntr_ok, nfr=ex["nfr"][ok],
-            est_cn=np.rint(ntr_ok / m_per_item).astype(np.int32),          # round(len(tr) / motif_size), half to even
-            read_off=np.concatenate(([0], np.cumsum(n_ok_per_locus))).astype(np.int32),
-            motifs=np.frombuffer(b"".join(motifs), np.uint8).copy(),
-            motif_off=np.concatenate(([0], np.cumsum([len(m) for m in motifs]))).astype(np.int32))
-        tm["extract_s"] += time.perf_counter() - t_a
-        t_a = time.perf_counter()
-        if batch.n_reads:
-            res = count_loci(batch, rc_params, ctx=ctx)
-            flt = filter_reads(batch, res, min_read_align_score)
-        else:
-            res = {k: np.zeros(0, np.int32) for k in ("cn", "score", "n_iters", "start")}
-            flt = {"sc": np.zeros(0), "keep": np.zeros(0, bool), "locus_ok": np.ones(batch.n_loci, bool)}
-        tm["count_s"] += time.perf_counter() - t_a
-        t_a = time.perf_counter()
-        ok_items = np.nonzero(ok)[0]
-        for li, (locus, rd) in enumerate(live):
-            r0, r1 = int(batch.read_off[li]), int(batch.read_off[li + 1])
-            kept = [r for r in range(r0, r1) if flt["keep"][r]]
-            reads = {}
-            for r in kept:
-                it = int(ok_items[r])
-                ri = int(rec[it])
-                sc = float(flt["sc"][r])
-                reads[bam.name(ri)] = {"s": bam.strand(ri), "cn": int(res["cn"][r]), "w": 1.0 / len(kept),
-                                       "sc": None if np.isnan(sc) else sc, "sl": int(batch.ntr[r]),
-                                       **({"realn": True} if alt and it in alt else {})}
-            row = _locus_dict(locus)
-            row["ref_cn"] = int(rd["ref_cn"])
-            if not respect_ref:
-                row["start_adj"], row["end_adj"] = rd["left_coord_adj"], rd["right_coord_adj"]
-            row["ref_start_anchor"] = rd["ref_left_flank_seq"][-VCF_ANCHOR_SIZE:].upper()
-            row["peaks"], row["read_peaks_called"] = None, False
-            row["reads"] = reads if flt["locus_ok"][li] else {}
-            n_depth += len(row["reads"])
-            results.append(row)
-        tm["extract_s"] += time.perf_counter() - t_a
-    results.sort(key=lambda r: r["locus_index"])
-    return results, n_depth, tm
+    t_a = time.perf_counter()
+    ex = extract_reads(bam, rec, coords, flank_size, opts.min_avg_phred, 3, alt)
+    ok = ex["status"] == 0
+    n_ok_per_locus = np.bincount(item_locus[ok], minlength=len(live))
+    motifs = [l.motif.encode() for l, _ in live]
+    m_per_item = np.array([len(m) for m in motifs], np.int64)[item_locus[ok]]
+    ntr_ok = ex["ntr"][ok]
+    batch = LocusBatch(
+        seqs=ex["seqs"], seq_off=np.concatenate(([0], ex["seq_off"][1:][ok])).astype(np.int64),
+        nfl=ex["nfl"][ok], ntr=ntr_ok, nfr=ex["nfr"][ok],
+        est_cn=np.rint(ntr_ok / m_per_item).astype(np.int32),          # round(len(tr) / motif_size), half to even
+        read_off=np.concatenate(([0], np.cumsum(n_ok_per_locus))).astype(np.int32),
+        motifs=np.frombuffer(b"".join(motifs), np.uint8).copy(),
+        motif_off=np.concatenate(([0], np.cumsum([len(m) for m in motifs]))).astype(np.int32))
+    tm["extract_s"] += time.perf_counter() - t_a
+    t_a = time.perf_counter()
+    res, flt = _count(batch, opts, ctx)
+    tm["count_s"] += time.perf_counter() - t_a
+    t_a = time.perf_counter()
+    ok_items = np.nonzero(ok)[0]
+    for li, (locus, rd) in enumerate(live):
+        r0, r1 = int(batch.read_off[li]), int(batch.read_off[li + 1])
+        kept = [r for r in range(r0, r1) if flt["keep"][r]]
+        reads = {}
+        for r in kept:
+            it = int(ok_items[r])
+            ri = int(rec[it])
+            sc = float(flt["sc"][r])
+            reads[bam.name(ri)] = {"s": bam.strand(ri), "cn": int(res["cn"][r]), "w": 1.0 / len(kept),
+                                   "sc": None if np.isnan(sc) else sc, "sl": int(batch.ntr[r]),
+                                   **({"realn": True} if alt and it in alt else {})}
+        row = _locus_row(locus, rd, reads if flt["locus_ok"][li] else {}, opts)
+        n_depth += len(row["reads"])
+        results.append(row)
+    tm["extract_s"] += time.perf_counter() - t_a
+    return results, n_depth
 
 
 def write_json(report: dict, path: str) -> None:

@@ -121,7 +121,9 @@ def get_read_coords_from_matched_pairs(left_flank_coord: int, left_coord: int, r
     if n == 0:
         return out
     out.full_left_flank = bool(ref_coords[0] <= left_flank_coord)
-    out.full_right_flank = bool(ref_coords[-1] >= right_flank_coord - 1)
+    # call_locus.py:907-909: skipped when right_flank_coord >= segment.end, i.e. the last aligned base (end - 1) must
+    # lie at or right of right_flank_coord
+    out.full_right_flank = bool(ref_coords[-1] >= right_flank_coord)
     if not (out.full_left_flank and out.full_right_flank):
         if not allow_only_one_full_flank or not (out.full_left_flank or out.full_right_flank):
             return out

@@ -4,6 +4,8 @@ from __future__ import annotations
 
 import gzip
 
+from .loci import resolve_contig
+
 __all__ = ["Fasta", "write_fasta"]
 
 
@@ -28,13 +30,13 @@ class Fasta:
         return list(self.seqs)
 
     def get_reference_length(self, contig: str) -> int:
-        return len(self.seqs[contig])
+        return len(self.seqs[resolve_contig(self.seqs, contig) or contig])
 
     def fetch(self, contig: str, start: int, end: int) -> str:
-        seq = self.seqs[contig]
+        seq = self.seqs[resolve_contig(self.seqs, contig) or contig]    # KeyError for an unknown contig (InvalidLocus)
         if start < 0 or start > len(seq):
             raise IndexError(f"{contig}:{start}-{end} out of range")
-        return seq[start:end].upper()
+        return seq[start:end]   # case kept, as pysam does: soft-masked reference stays lower case (docs/output_formats.md:96)
 
 
 def write_fasta(path: str, seqs: dict[str, str], width: int = 60) -> None:

@@ -7,11 +7,29 @@ from dataclasses import dataclass
 from typing import Iterable, Iterator
 
 __all__ = ["Locus", "LocusValidationError", "valid_motif", "validate_locus", "parse_loci_bed", "parse_last_column",
-           "load_loci", "MAX_BLOCK_SIZE", "MAX_BLOCK_INTER_READ_DIST"]
+           "load_loci", "normalize_contig", "resolve_contig", "MAX_BLOCK_SIZE", "MAX_BLOCK_INTER_READ_DIST"]
 
 _IUPAC_MOTIF_LETTERS = frozenset("ACGTRYSWKMBDHVN")   # loci.py:30: nucleotide codes, no 'X', no lower case
 MAX_BLOCK_SIZE = 200                                   # loci.py:193
 MAX_BLOCK_INTER_READ_DIST = 20000                      # loci.py:194
+
+
+def normalize_contig(contig: str, has_chr: bool) -> str:
+    """The name of `contig` in a file whose contigs do (has_chr) or do not carry the "chr" prefix — what the reference's
+    `normalize_contig(locus.contig, ref_file_has_chr)` does between catalog, alignment file and reference genome
+    (call_locus.py:758; `ref_file_has_chr` = any contig starts with "chr", call_sample.py:312)."""
+    if has_chr:
+        return contig if contig.startswith("chr") else "chr" + contig
+    return contig[3:] if contig.startswith("chr") else contig
+
+
+def resolve_contig(names, contig: str) -> str | None:
+    """`contig` as one of `names` (a container of a file's contig names), with or without the "chr" prefix; None when
+    the file does not have it either way."""
+    if contig in names:
+        return contig
+    alt = normalize_contig(contig, not contig.startswith("chr"))
+    return alt if alt in names else None
 
 
 class LocusValidationError(ValueError):
@@ -107,6 +125,8 @@ def load_loci(loci_file: str, flank_size: int = 70, contigs: Iterable[str] | Non
     rows = list(parse_loci_bed(loci_file))
     cap = max_block_size or min(MAX_BLOCK_SIZE, max(len(rows) // max(processes, 1), 1))
     known = set(contigs) if contigs is not None else None
+    if known is not None:       # "chr1" in the catalog and "1" in the files (or the reverse) are the same contig
+        known |= {normalize_contig(c, True) for c in known} | {normalize_contig(c, False) for c in known}
     blocks: list[list[Locus]] = []
     cur: list[Locus] = []
     cur_right = -1

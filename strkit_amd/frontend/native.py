@@ -9,7 +9,8 @@ import struct
 import numpy as np
 
 from .. import _lib
-from .bam import AlignedSegment
+from .bam import AlignedSegment, real_cigar
+from .loci import resolve_contig
 
 __all__ = ["NativeBam", "extract_reads", "realign_cigar_to_read_alignment", "bgzf_read"]
 
@@ -78,7 +79,8 @@ class NativeBam:
 
     def fetch_indices(self, contig: str, start: int, end: int) -> np.ndarray:
         """Indices of the mapped records that overlap [start, end), in coordinate order."""
-        if contig not in self._by_contig:
+        contig = resolve_contig(self._by_contig, contig)
+        if contig is None:
             return np.zeros(0, np.int64)
         pos, rend, idx = self._by_contig[contig]
         hi = int(np.searchsorted(pos, end, side="left"))
@@ -110,8 +112,10 @@ class NativeBam:
         p += (l_seq + 1) // 2
         qual = raw[p:p + l_seq].copy()
         tid = int(self.tid[i])
+        block, = struct.unpack_from("<i", raw, o - 4)
+        tags = raw[p + l_seq:o + block].tobytes()
         return AlignedSegment(self.name(i), int(self.flag[i]), self.contigs[tid][0] if tid >= 0 else "*", int(self.pos[i]),
-                              int(raw[o + 9]), cigar, seq, None if l_seq and qual[0] == 0xFF else qual)
+                              int(raw[o + 9]), real_cigar(cigar, l_seq, tags), seq, None if l_seq and qual[0] == 0xFF else qual, tags)
 
     def soft_clip_overlaps(self, idx: np.ndarray, left_flank_coord: int, right_flank_coord: int) -> np.ndarray:
         """AlignedSegment.soft_clip_overlaps_locus for many records."""
@@ -141,9 +145,6 @@ def extract_reads(bam: NativeBam, rec_idx: np.ndarray, coords: np.ndarray, flank
     coords = np.ascontiguousarray(coords, np.int64).reshape(n, 4)
     status, nfl, ntr, nfr = (np.zeros(n, np.int32) for _ in range(4))
     seq_off = np.zeros(n + 1, np.int64)
-    cap = int(np.minimum(bam.l_seq[rec_idx].astype(np.int64), (coords[:, 3] - coords[:, 0]) * 4 + 64).sum()) + 16 if n else 16
-    cap = max(cap, int(bam.l_seq[rec_idx].astype(np.int64).sum()) + 16) if alt else cap
-    seqs = np.zeros(cap, np.uint8)
     a_cig = a_off = a_start = None
     if alt:
         a_off = np.zeros(n + 1, np.int64)
@@ -158,11 +159,19 @@ def extract_reads(bam: NativeBam, rec_idx: np.ndarray, coords: np.ndarray, flank
                 a_off[i + 1] = a_off[i]
         a_cig = np.concatenate(parts) if parts else np.zeros(1, np.uint32)
     L = _lib.load()
-    rc = L.strk_extract_reads(bam.data.ctypes.data, bam.data.size, n, rec_off.ctypes.data, coords.ctypes.data,
-                              a_cig.ctypes.data if a_cig is not None else None,
-                              a_off.ctypes.data if a_off is not None else None,
-                              a_start.ctypes.data if a_start is not None else None,
-                              int(flank_size), int(min_avg_phred), int(wildcard_threshold), status.ctypes.data,
-                              nfl.ctypes.data, ntr.ctypes.data, nfr.ctypes.data, seqs.ctypes.data, cap, seq_off.ctypes.data)
-    _lib.check(rc)
+
+    def call(seqs_ptr, cap):
+        return L.strk_extract_reads(bam.data.ctypes.data, bam.data.size, n, rec_off.ctypes.data, coords.ctypes.data,
+                                    a_cig.ctypes.data if a_cig is not None else None,
+                                    a_off.ctypes.data if a_off is not None else None,
+                                    a_start.ctypes.data if a_start is not None else None,
+                                    int(flank_size), int(min_avg_phred), int(wildcard_threshold), status.ctypes.data,
+                                    nfl.ctypes.data, ntr.ctypes.data, nfr.ctypes.data, seqs_ptr, cap, seq_off.ctypes.data)
+
+    # size query first: a read may carry an expansion many times the reference window (the flagship case), so the
+    # buffer is sized by what the reads actually hold, not by the locus
+    _lib.check(call(None, 0))
+    cap = int(seq_off[-1]) + 16
+    seqs = np.empty(cap, np.uint8)
+    _lib.check(call(seqs.ctypes.data, cap))
     return {"status": status, "nfl": nfl, "ntr": ntr, "nfr": nfr, "seqs": seqs[:int(seq_off[-1])], "seq_off": seq_off}

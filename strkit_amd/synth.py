@@ -13,7 +13,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-__all__ = ["LocusBatch", "make_batch", "CONFIGS", "make_config"]
+__all__ = ["LocusBatch", "make_batch", "make_catalog_batch", "CONFIGS", "make_config"]
 
 _BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
 _X = ord("X")
@@ -62,6 +62,23 @@ class LocusBatch:
             nfr=self.nfr[r0:r1], est_cn=self.est_cn[r0:r1], read_off=self.read_off[lo:hi + 1] - r0,
             motifs=self.motifs[m0:m1], motif_off=self.motif_off[lo:hi + 1] - m0,
             true_cn=None if self.true_cn is None else self.true_cn[r0:r1])
+
+    @staticmethod
+    def concat(parts: "list[LocusBatch]") -> "LocusBatch":
+        """The loci of `parts`, in order, as one batch."""
+        def offs(arrs, dtype):
+            out, base = [np.zeros(1, dtype)], 0
+            for a in arrs:
+                out.append(a[1:].astype(dtype) + base)
+                base += int(a[-1])
+            return np.concatenate(out)
+        tc = None if any(p.true_cn is None for p in parts) else np.concatenate([p.true_cn for p in parts])
+        return LocusBatch(
+            seqs=np.concatenate([p.seqs for p in parts]), seq_off=offs([p.seq_off for p in parts], np.int64),
+            nfl=np.concatenate([p.nfl for p in parts]), ntr=np.concatenate([p.ntr for p in parts]),
+            nfr=np.concatenate([p.nfr for p in parts]), est_cn=np.concatenate([p.est_cn for p in parts]),
+            read_off=offs([p.read_off for p in parts], np.int32), motifs=np.concatenate([p.motifs for p in parts]),
+            motif_off=offs([p.motif_off for p in parts], np.int32), true_cn=tc)
 
     def algorithmic_bytes(self) -> int:
         """per read |fl|+|tr|+|fr| + 4 in, 12 out; per locus |motif| + 8."""
@@ -121,13 +138,24 @@ def _mutate(rng: np.random.Generator, seq: np.ndarray, sub: float, indel: float,
 
 
 def make_batch(seed: int, n_loci: int, reads_per_locus: int, motif_len: tuple[int, int], cn_range: tuple[int, int],
-               sub: float, indel: float, xrate: float, flank: int = 70, slip: float = 0.0) -> LocusBatch:
+               sub: float, indel: float, xrate: float, flank: int = 70, slip: float = 0.0,
+               motif_mix: tuple[tuple[tuple[int, int], float], ...] | None = None) -> LocusBatch:
+    """`motif_mix` (optional) = ((length range, probability), ...): the motif length is drawn from a mixture of ranges
+    (1-6 bp with probability 0.7, 7-20 bp with 0.3) instead of uniformly from `motif_len`."""
     rng = np.random.default_rng(seed)
     loci = []
     true_cn = []
     for _ in range(n_loci):
+        ml_range = motif_len
+        if motif_mix is not None:
+            u, acc = rng.random(), 0.0
+            for rg, pr in motif_mix:
+                acc += pr
+                ml_range = rg
+                if u < acc:
+                    break
         while True:
-            m = _BASES[rng.integers(4, size=int(rng.integers(motif_len[0], motif_len[1] + 1)))]
+            m = _BASES[rng.integers(4, size=int(rng.integers(ml_range[0], ml_range[1] + 1)))]
             if len(m) == 1 or not _reducible(m):
                 break
         ml = len(m)
@@ -155,6 +183,48 @@ def make_batch(seed: int, n_loci: int, reads_per_locus: int, motif_len: tuple[in
     return b
 
 
+# code -> member bases, as the reference has it (strkit/iupac.py:9-21, including "D" = A, C, T)
+_IUPAC = {"R": "AG", "Y": "CT", "S": "CG", "W": "AT", "K": "GT", "M": "AC", "B": "CGT", "D": "ACT", "H": "ACT",
+          "V": "ACG", "N": "ACGT"}
+
+
+def make_catalog_batch(loci: list[tuple[str, int]], seed: int, reads_per_locus: int = 30, sub: float = 0.001,
+                       indel: float = 0.002, xrate: float = 0.0005, flank: int = 70, slip: float = 0.02) -> LocusBatch:
+    """BASELINE.json config 1's shape: loci of a real catalog (`loci` = [(motif, reference tract length), ...], e.g. the
+    44 loci of catalogs/pathogenic_assoc.hg38.tsv, whose motifs include IUPAC codes such as AARRG or GCN) over a
+    synthetic genome.  Every copy of an IUPAC motif draws its own member bases, the way such repeats vary between
+    copies; reads carry the HiFi error model of config 2."""
+    rng = np.random.default_rng(seed)
+    out, true_cn = [], []
+    for motif, ref_len in loci:
+        ml = len(motif)
+        choices = [np.frombuffer(_IUPAC.get(ch, ch).encode(), np.uint8) for ch in motif]
+
+        def copies(n):
+            if n <= 0:
+                return np.zeros(0, np.uint8)
+            return np.stack([c[rng.integers(len(c), size=n)] for c in choices], axis=1).reshape(-1)
+
+        fl = _BASES[rng.integers(4, size=flank)]
+        fr = _BASES[rng.integers(4, size=flank)]
+        ref_cn = max(1, round(ref_len / ml))
+        alleles = [max(1, ref_cn + int(s) * int(rng.geometric(0.5) - 1)) for s in rng.choice((-1, 1), size=2)]
+        tracts = [copies(a) for a in alleles]               # one haplotype sequence per allele
+        reads = []
+        for r in range(reads_per_locus):
+            tr, cn = tracts[r & 1], alleles[r & 1]
+            if slip and rng.random() < slip:                 # in-tract motif-unit slippage
+                d = int(rng.choice((-1, 1)))
+                tr = np.concatenate([tr, copies(1)]) if d > 0 else tr[:max(ml, len(tr) - ml)]
+                cn = max(1, cn + d)
+            reads.append(tuple(_mutate(rng, x, sub, indel, xrate).tobytes().decode() for x in (fl, tr, fr)))
+            true_cn.append(cn)
+        out.append((motif, reads))
+    b = LocusBatch.from_reads(out)
+    b.true_cn = np.array(true_cn, np.int32)
+    return b
+
+
 # BASELINE.json configs (SURVEY.md §8d).  cfg1 is CPU plumbing only; cfg4/5 are the 8-GPU shapes.
 CONFIGS = {
     1: dict(n_loci=44, reads_per_locus=30, motif_len=(3, 6), cn_range=(5, 60), sub=0.001, indel=0.002, xrate=0.0005,
@@ -162,8 +232,8 @@ CONFIGS = {
     2: dict(n_loci=1000, reads_per_locus=30, motif_len=(3, 6), cn_range=(5, 60), sub=0.001, indel=0.002,
             xrate=0.0005, slip=0.02),
     3: dict(n_loci=10000, reads_per_locus=20, motif_len=(2, 20), cn_range=(5, 60), sub=0.03, indel=0.04, xrate=0.01),
-    4: dict(n_loci=170000, reads_per_locus=30, motif_len=(1, 6), cn_range=(5, 60), sub=0.001, indel=0.002,
-            xrate=0.0005, slip=0.02),
+    4: dict(n_loci=170000, reads_per_locus=30, motif_len=(1, 20), motif_mix=(((1, 6), 0.7), ((7, 20), 0.3)),
+            cn_range=(5, 60), sub=0.001, indel=0.002, xrate=0.0005, slip=0.02),
     5: dict(n_loci=2000, reads_per_locus=40, motif_len=(1, 6), cn_range=(50, 2000), sub=0.001, indel=0.002,
             xrate=0.0005, slip=0.02),
 }

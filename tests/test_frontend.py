@@ -92,9 +92,9 @@ def test_read_coordinates_put_boundary_insertions_into_the_tract():
     # ref: flank [0,10) tract [10,16) flank [16,26); read has 6 extra bases inserted right after the tract's last base
     class Seg:
         start = 0
-        cigar = np.array([(16 << 4) | 0, (6 << 4) | 1, (10 << 4) | 0], np.uint32)
-        query_sequence = "A" * 10 + "CAGCAG" + "CAGCAG" + "T" * 10
-        query_qualities = np.full(32, 30)
+        cigar = np.array([(16 << 4) | 0, (6 << 4) | 1, (11 << 4) | 0], np.uint32)
+        query_sequence = "A" * 10 + "CAGCAG" + "CAGCAG" + "T" * 11
+        query_qualities = np.full(33, 30)
     q, r = get_aligned_pairs(Seg)
     c = get_read_coords_from_matched_pairs(0, 10, 16, 26, q, r)
     assert (c.left_flank_start, c.left_flank_end, c.right_flank_start, c.right_flank_end) == (0, 10, 22, 32)
@@ -102,13 +102,19 @@ def test_read_coordinates_put_boundary_insertions_into_the_tract():
     assert (sd.flank_left_seq_wc, sd.tr_seq_wc, sd.flank_right_seq_wc, sd.tr_len_with_flank) == ("A" * 10, "CAG" * 4, "T" * 10, 32)
     assert sd.get_est_copy_num(3) == 4
     # ... and right before its first base; a read that stops short of a flank end is incomplete
-    Seg.cigar = np.array([(10 << 4) | 0, (6 << 4) | 1, (16 << 4) | 0], np.uint32)
+    Seg.cigar = np.array([(10 << 4) | 0, (6 << 4) | 1, (17 << 4) | 0], np.uint32)
     q, r = get_aligned_pairs(Seg)
     c = get_read_coords_from_matched_pairs(0, 10, 16, 26, q, r)
     assert (c.left_flank_end, c.right_flank_start) == (10, 22)
     assert get_read_coords_from_matched_pairs(0, 10, 16, 40, q, r).is_incomplete()
+    # call_locus.py:907-909: a read is skipped when right_flank_coord >= segment.end - here the alignment ends at
+    # reference position 27 (exclusive), so right_flank_coord 26 is the last one that still counts as spanned
+    assert not get_read_coords_from_matched_pairs(0, 10, 16, 26, q, r).is_incomplete()
+    assert get_read_coords_from_matched_pairs(0, 10, 16, 27, q, r).is_incomplete()
+    assert get_read_coords_from_matched_pairs(1, 10, 16, 26, q, r).full_left_flank
+    assert not get_read_coords_from_matched_pairs(-1, 10, 16, 26, q, r).full_left_flank
     # low-quality tract bases: wildcards at <= 3, LowMeanBaseQual under the mean threshold
-    Seg.query_qualities = np.full(32, 30)
+    Seg.query_qualities = np.full(33, 30)
     Seg.query_qualities[12:14] = 2
     assert get_sequence_data_for_locus(Seg, c, 10).tr_seq_wc == "CAXXAGCAGCAG"
     Seg.query_qualities[10:22] = 5
@@ -264,3 +270,105 @@ def test_parallel_bgzf_inflate(tmp_path):
     raw = np.fromfile(plain, np.uint8)
     assert L.strk_bgzf_inflate(raw.ctypes.data, raw.size, None, 0, 0) < 0
     assert np.array_equal(bgzf_read(plain), want[:5000])
+
+
+def _expansion_bam(tmp_path, n_reads=30, n_expanded=15, ins=3000, long_cigar=False):
+    """One sparse locus (a block of its own): 30 bp reference tract, flank 70; half of the reads carry an insertion a
+    hundred times the reference window (the flagship large-expansion case)."""
+    from strkit_amd.frontend.bam import write_bam
+    rng = np.random.default_rng(17)
+    rnd = lambda n: "".join("ACGT"[i] for i in rng.integers(4, size=n))  # noqa: E731
+    left, right = rnd(600), rnd(600)
+    ref = left + "CAG" * 10 + right
+    recs = []
+    for i in range(n_reads):
+        if i < n_expanded:
+            seq = left + "CAG" * 10 + "CAG" * (ins // 3) + right
+            cigar = [(630, "="), (ins, "I"), (600, "=")]
+        else:
+            seq, cigar = ref, [(1230, "=")]
+        recs.append(dict(name=f"r{i}", flag=0, contig="chr1", pos=0, cigar=cigar, seq=seq, qual=np.full(len(seq), 40),
+                         long_cigar=long_cigar and i % 2 == 0))
+    path = str(tmp_path / "exp.bam")
+    write_bam(path, [("chr1", len(ref))], recs)
+    return path, ref
+
+
+@pytest.mark.parametrize("long_cigar", [False, True])
+def test_large_expansions_do_not_overflow_the_extraction_buffer(tmp_path, long_cigar):
+    """A read may hold many times the reference window (a 4x bound made strk_extract_reads fail with
+    STRK_E_NOMEM and aborted the sample); the buffer is now sized by a size query.  With long_cigar every other record
+    stores its CIGAR the way alignments with more than 65 535 operations do (placeholder + CG:B,I tag)."""
+    from strkit_amd.frontend import NativeBam, extract_reads, get_read_coords_from_cigar
+    path, _ = _expansion_bam(tmp_path, long_cigar=long_cigar)
+    nb, pb = NativeBam(path), read_bam(path)
+    idx = nb.fetch_indices("chr1", 530, 700)
+    assert len(idx) == 30
+    c4 = (530, 600, 630, 700)
+    ex = extract_reads(nb, idx, np.tile(c4, (30, 1)), 70, 13)
+    assert (ex["status"] == 0).all() and sorted(set(ex["ntr"].tolist())) == [30, 3030]
+    for k, s in enumerate(pb.fetch("chr1", 530, 700)):
+        s2 = nb.segment(int(idx[k]))
+        assert np.array_equal(s2.cigar, s.cigar) and (s.end, nb.end[idx[k]]) == (1230, 1230) and len(s.cigar) in (1, 3)
+        sd = get_sequence_data_for_locus(s, get_read_coords_from_cigar(*c4, s), 70)
+        assert ex["seqs"][ex["seq_off"][k]:ex["seq_off"][k + 1]].tobytes().decode() == \
+            sd.flank_left_seq_wc[-70:] + sd.tr_seq_wc + sd.flank_right_seq_wc[:70]
+    # size query (seqs == NULL) and a buffer one byte short
+    import ctypes as C
+    from strkit_amd import _lib
+    L = _lib.load()
+    n = 30
+    rec_off = np.ascontiguousarray(nb.rec_off[idx], np.int64)
+    coords = np.ascontiguousarray(np.tile(c4, (n, 1)), np.int64)
+    st, a, b, c = (np.zeros(n, np.int32) for _ in range(4))
+    off = np.zeros(n + 1, np.int64)
+    args = (nb.data.ctypes.data, nb.data.size, n, rec_off.ctypes.data, coords.ctypes.data, None, None, None, 70, 13, 3,
+            st.ctypes.data, a.ctypes.data, b.ctypes.data, c.ctypes.data)
+    assert L.strk_extract_reads(*args, None, 0, off.ctypes.data) == 0 and off[-1] == ex["seq_off"][-1]
+    buf = np.zeros(int(off[-1]), np.uint8)
+    assert L.strk_extract_reads(*args, buf.ctypes.data, buf.size - 1, off.ctypes.data) == -12   # STRK_E_NOMEM
+    assert L.strk_extract_reads(*args, buf.ctypes.data, buf.size, off.ctypes.data) == 0 and np.array_equal(buf, ex["seqs"])
+
+
+def test_threaded_extraction_equals_the_serial_one(tmp_path):
+    """More than 512 items take the multi-threaded path of strk_extract_reads: same bytes as item-by-item calls."""
+    from strkit_amd.frontend import NativeBam, extract_reads
+    t = make_dataset(str(tmp_path), n_loci=40, reads_per_locus=20, read_len=1200, seed=12, sub=0.01, indel=0.01, low_qual=0.02)
+    nb = NativeBam(t["paths"]["bam"])
+    (block,) = load_loci(t["paths"]["loci"])
+    rec, coords = [], []
+    for locus in block:
+        idx = nb.fetch_indices(locus.contig, locus.left_flank_coord, locus.right_flank_coord)
+        rec.append(idx)
+        coords.append(np.tile([locus.left_flank_coord, locus.left_coord, locus.right_coord, locus.right_flank_coord], (len(idx), 1)))
+    rec, coords = np.concatenate(rec), np.concatenate(coords)
+    assert len(rec) > 700
+    whole = extract_reads(nb, rec, coords, 70, 13)
+    parts = [extract_reads(nb, rec[i:i + 100], coords[i:i + 100], 70, 13) for i in range(0, len(rec), 100)]
+    assert np.array_equal(whole["seqs"], np.concatenate([p["seqs"] for p in parts]))
+    for k in ("status", "nfl", "ntr", "nfr"):
+        assert np.array_equal(whole[k], np.concatenate([p[k] for p in parts]))
+
+
+def test_report_diff_logic():
+    """strkit_amd/frontend/compare.py: the STRkit-JSON diff that tools/compare_strkit_json.py prints."""
+    from strkit_amd.frontend.compare import diff_reports, format_diff
+    theirs = {"parameters": {"rc_method": "repalign"}, "results": [
+        {"locus_index": 1, "contig": "chr4", "start": 96617, "end": 96648, "motif": "AC", "ref_cn": 16, "start_adj": 96617,
+         "end_adj": 96648, "reads": {"r1": {"s": "-", "sc": 2.0, "cn": 15, "w": 1.02}, "r2": {"s": "+", "sc": 1.9, "cn": 16},
+                                     "r3": {"s": "+", "sc": None, "cn": 0}}},
+        {"locus_index": 2, "contig": "chr4", "start": 200, "end": 230, "motif": "CAG", "ref_cn": 10, "reads": {}}]}
+    ours = {"results": [
+        {"locus_index": 7, "contig": "4", "start": 96617, "end": 96648, "motif": "ac", "ref_cn": 16, "start_adj": 96617,
+         "end_adj": 96650, "reads": {"r1": {"s": "-", "sc": 2.0, "cn": 15, "w": 0.5}, "r2": {"s": "+", "sc": 1.8, "cn": 17},
+                                     "r4": {"s": "+", "sc": 2.0, "cn": 15}}},
+        {"locus_index": 9, "contig": "chr5", "start": 1, "end": 9, "motif": "A", "ref_cn": 8, "reads": {}}]}
+    d = diff_reports(theirs, ours)
+    assert (d["loci_common"], d["loci_only_theirs"], d["loci_only_ours"]) == (1, 1, 1)           # "chr4" == "4", motif case
+    assert (d["locus_fields_compared"], d["locus_fields_equal"]) == (3, 2)                        # end_adj differs
+    assert (d["reads_common"], d["reads_only_theirs"], d["reads_only_ours"], d["cn_equal"]) == (2, 1, 1, 1)
+    assert (d["sc_compared"], d["sc_equal"]) == (2, 1) and not d["identical"]
+    assert {x["kind"] for x in d["diffs"]} == {"end_adj", "cn", "sc", "read missing in ours", "locus missing in ours"}
+    assert "DIFFERENT" in format_diff(d)
+    same = diff_reports(theirs, theirs)
+    assert same["identical"] and same["diffs"] == [] and same["sc_compared"] == 2

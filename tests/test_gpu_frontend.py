@@ -84,3 +84,64 @@ def test_cli_writes_json(gpu_ctx, tmp_path):
     assert main(["call", t["paths"]["bam"], "--ref", t["paths"]["ref"], "--loci", t["paths"]["loci"], "--json", out,
                  "--processes", "2", "--max-rcn-iters", "30", "--min-read-align-score", "0.2", "--sample-id", "s1", "--seed", "7"]) == 0
     assert json.load(open(out))["sample_id"] == "s1"
+
+
+def test_compare_tool_finds_the_generating_switches(gpu_ctx, tmp_path):
+    """tools/compare_strkit_json.py on a report that plays STRkit's: a report made with tie_rule = last-maximum and a
+    one-sided end-gap mode is reproduced by exactly that combination of the sweep, and the plain diff against the
+    default switches sees the differing reads."""
+    import importlib.util
+    import os
+    from strkit_amd.frontend.compare import diff_reports
+    t = make_dataset(str(tmp_path), n_loci=14, reads_per_locus=8, read_len=1500, seed=21, sub=0.02, indel=0.03, motif_len=(1, 3))
+    theirs = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"], tie_rule=1, end_flags=5)
+    theirs["parameters"]["rc_method"] = "repalign"
+    path = str(tmp_path / "strkit.json")
+    json.dump(theirs, open(path, "w"))
+    default = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"])
+    d = diff_reports(theirs, default)
+    assert d["loci_common"] == 14 and d["locus_fields_equal"] == d["locus_fields_compared"]   # the reference side has no switch
+    assert not d["identical"] and d["cn_equal"] + d["sc_equal"] < d["reads_common"] + d["sc_compared"]
+    spec = importlib.util.spec_from_file_location("cmp_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "compare_strkit_json.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    out = str(tmp_path / "sweep.json")
+    rc = tool.main([path, "--bam", t["paths"]["bam"], "--ref", t["paths"]["ref"], "--loci", t["paths"]["loci"], "--sweep", "--json", out])
+    rows = json.load(open(out))
+    assert rc == 0 and len(rows) == 32 and rows[0]["identical"]
+    assert (5, 1) in {(r["end_flags"], r["tie_rule"]) for r in rows if r["identical"]}
+    assert tool.main([path, "--ours", path]) == 0
+    ours_path = str(tmp_path / "ours.json")
+    json.dump(default, open(ours_path, "w"))
+    assert tool.main([path, "--ours", ours_path]) == 1
+
+
+def test_large_expansion_reads_are_called(gpu_ctx, tmp_path):
+    """One sparse locus whose reads carry a 1 000-copy insertion (a hundred times the reference window): round 1's
+    extraction buffer bound made the library fail and the whole sample abort."""
+    from test_frontend import _expansion_bam
+    from strkit_amd.frontend.fasta import write_fasta
+    path, ref = _expansion_bam(tmp_path)
+    write_fasta(str(tmp_path / "ref.fa"), {"chr1": ref})
+    (tmp_path / "loci.bed").write_text("chr1\t600\t630\tCAG\n")
+    rep = call_sample(path, str(tmp_path / "ref.fa"), str(tmp_path / "loci.bed"))
+    (row,) = rep["results"]
+    assert rep["errors"] == [] and row["ref_cn"] == 10 and len(row["reads"]) == 30
+    assert sorted({rd["cn"] for rd in row["reads"].values()}) == [10, 1010]
+    assert all(rd["sc"] == 2.0 for rd in row["reads"].values())
+
+
+def test_chr_prefix_is_normalised_between_catalog_and_files(gpu_ctx, tmp_path):
+    """call_locus.py:758 normalize_contig: a catalog written with "chr1" against files that say "1" (and the reverse)."""
+    t = make_dataset(str(tmp_path), n_loci=5, reads_per_locus=4, read_len=1200, seed=6)
+    base = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"])
+    assert len(base["results"]) == 5
+    rows = open(t["paths"]["loci"]).read().splitlines()
+    contig = rows[0].split("\t")[0]
+    other = contig[3:] if contig.startswith("chr") else "chr" + contig
+    alt = str(tmp_path / "alt.bed")
+    open(alt, "w").write("\n".join(other + r[len(contig):] for r in rows) + "\nchrNope\t10\t40\tCAG\n")
+    rep = call_sample(t["paths"]["bam"], t["paths"]["ref"], alt)
+    assert rep["catalog"] == {"num_loci": 5, "num_loci_unknown_contig": 1}
+    for a, b in zip(base["results"], rep["results"]):
+        assert {**a, "contig": None} == {**b, "contig": None} and b["contig"] == other

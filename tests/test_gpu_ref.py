@@ -112,3 +112,49 @@ def test_batched_reference_side_equals_scalar_and_oracle(gpu_ctx):
                                           rc.initial_step_size, respect)
             assert got == exp
     assert get_ref_repeat_counts([], 5) == []
+
+
+def _docs_anchor_locus(seed):
+    """The one result the reference's tree holds for this path: docs/output_formats.md:92-104 — motif AC, the 31-base
+    soft-masked tract `acac...a`, `ref_cn: 16`, `start_adj == start`, `end_adj == end`.  The read side of that sample
+    used rc_method "comp", but the reference side ALWAYS runs repalign (call_locus.py:799-810), so 16 is an answer of
+    get_ref_repeat_count.  The flanks are not printed there: any flank that does not continue the repeat will do."""
+    rng = np.random.default_rng(seed)
+    fl = "".join("acgt"[i] for i in rng.integers(4, size=69)) + "t"      # "ref_start_anchor": "t"
+    fr = "g" + "".join("acgt"[i] for i in rng.integers(4, size=69))
+    return fl, ("ac" * 16)[:31], fr
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_docs_anchor_ref_cn_16(gpu_ctx, seed):
+    from strkit_amd.repeats import get_ref_repeat_count
+    fl, tr, fr = _docs_anchor_locus(seed)
+    est = round(len(tr) / 2)
+    rc = get_reference_rc_params("repalign", est, 250)
+    (cn, score), l_off, r_off, n_is, (fl2, tr2, fr2) = get_ref_repeat_count(est, tr, fl, fr, "AC", 31, 5, rc)
+    assert cn == 16 and max(0, l_off) == 0 and max(0, r_off) == 0      # ref_cn 16, start_adj/end_adj unchanged
+    assert tr2 == tr                                                     # "ref_seq" keeps the soft-masked case
+    assert ((cn, score), l_off, r_off, n_is, (fl2, tr2, fr2)) == oracle.ref_repeat_count(
+        est, tr, fl, fr, "AC", 31, 5, rc.max_iters, rc.initial_local_search_range, rc.initial_step_size)
+
+
+def test_long_boundary_search_runs_250_iterations(gpu_ctx, tmp_path):
+    """call_locus.py:71: default_ref_max_iters = 250.  A homopolymer that runs 125 bases past the catalog's right
+    coordinate (flank size 160) needs more than 100 offset scores: with a limit of 100 the search stops at +99."""
+    from strkit_amd.frontend import Fasta
+    from strkit_amd.frontend.call import DEFAULT_REF_MAX_ITERS, get_locus_with_ref_data
+    from strkit_amd.frontend.fasta import write_fasta
+    from strkit_amd.frontend.loci import Locus
+    assert DEFAULT_REF_MAX_ITERS == 250
+    rng = np.random.default_rng(3)
+    rnd = lambda n: "".join("CGT"[i] for i in rng.integers(3, size=n))  # noqa: E731
+    F = 160
+    fl, tr, fr = rnd(F), "A" * 20, "A" * 125 + rnd(F - 125)
+    chrom = rnd(500) + fl + tr + fr + rnd(500)
+    write_fasta(str(tmp_path / "ref.fa"), {"chr1": chrom})
+    locus = Locus(1, "locus1", "chr1", 500 + F, 500 + F + 20, "A", F)
+    rd = get_locus_with_ref_data(locus, Fasta(str(tmp_path / "ref.fa")), context=gpu_ctx)
+    exp = {mi: oracle.ref_repeat_count(20, tr, fl, fr, "A", 20, 5, mi, 3, 1) for mi in (100, 250)}
+    assert exp[100][2] == 99 and exp[250][2] == 125 and exp[250][3][0] > 100
+    assert (rd["ref_cn"], rd["right_coord_adj"] - locus.right_coord, rd["left_coord_adj"]) == (exp[250][0][0], 125, locus.left_coord)
+    assert (rd["ref_left_flank_seq"], rd["ref_seq"], rd["ref_right_flank_seq"]) == exp[250][4]

@@ -88,6 +88,24 @@ def test_partial_copy_rounds_up_under_alignment_scoring():
     assert oracle.candidate_score(tr, fl, fr, "AC", 15) == 2 * (len(fl) + 30 + len(fr)) - 5
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_docs_anchor_ref_cn_16(seed):
+    """The only result the reference's tree holds for this path (docs/output_formats.md:92-104): motif AC, 31-base
+    soft-masked tract `acac...a`, `ref_cn: 16`, `start_adj == start`, `end_adj == end`.  ref_cn always comes from
+    get_ref_repeat_count with repalign (call_locus.py:799-810), whatever rc_method the reads used."""
+    from strkit_amd.repeat_count_params import get_reference_rc_params
+    rng = np.random.default_rng(seed)
+    fl = "".join("acgt"[i] for i in rng.integers(4, size=69)) + "t"
+    fr = "g" + "".join("acgt"[i] for i in rng.integers(4, size=69))
+    tr = ("ac" * 16)[:31]
+    est = round(31 / 2)
+    assert est == 16
+    rc = get_reference_rc_params("repalign", est, 250)       # call_locus.py:71,808
+    (cn, _), l_off, r_off, _, (_, tr2, _) = oracle.ref_repeat_count(est, tr, fl, fr, "AC", 31, 5, rc.max_iters,
+                                                                    rc.initial_local_search_range, rc.initial_step_size)
+    assert cn == 16 and max(0, l_off) == 0 and max(0, r_off) == 0 and tr2 == tr
+
+
 def test_tie_rules_differ_only_on_ties():
     rng = np.random.default_rng(5)
     seen_diff = False
