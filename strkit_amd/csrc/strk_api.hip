@@ -43,7 +43,8 @@ std::atomic<int> g_calls_in_flight{0};
 // Default candidate window of this process (one sample, whatever context a call runs on): level into kWindowLevels,
 // and the number of consecutive default-window calls without a window miss since the level last changed.
 // Misses cost extra rounds on the host: a call with more than a handful (> 0.4 % of its loci) moves a level up at
-// once; eight (from the two widest levels: sixty-four) calls in a row without any move a level down.
+// once; eight (from the two widest levels: sixty-four) calls in a row with at most one miss per two thousand loci move
+// a level down.
 std::atomic<int> g_win_level{1};
 std::atomic<int> g_win_quiet{0};
 
@@ -199,6 +200,8 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
     a.long_slot = (long long)kLongSlotInts;
     a.long_waves = kLongWaves;
     a.list_stride = list_stride;
+    static const int dbg = getenv("STRKIT_AMD_DBG") ? atoi(getenv("STRKIT_AMD_DBG")) : 0;
+    a.dbg = dbg;
     a.end_flags = end_flags;
     a.window = window;
     a.table_stride = table_stride;
@@ -367,7 +370,7 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         if (n_miss > std::max(2, b->n_loci / 250)) {
             if (level < 3) g_win_level.store(level + 1, std::memory_order_relaxed);
             g_win_quiet.store(level == 0 ? -56 : 0, std::memory_order_relaxed);   // a failed narrow window is not retried soon
-        } else if (n_miss > 0) {
+        } else if (n_miss > b->n_loci / 2000) {   // more than one locus in two thousand: not a quiet call
             g_win_quiet.store(0, std::memory_order_relaxed);
         } else if (g_win_quiet.fetch_add(1, std::memory_order_relaxed) + 1 >= (level >= 2 ? 64 : 8) && level > 0) {
             g_win_level.store(level - 1, std::memory_order_relaxed);

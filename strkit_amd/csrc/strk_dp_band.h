@@ -22,7 +22,7 @@ struct BandLayout {
     // behind, sized so that no column the two passes can ask for (virtual rows, rows beyond |db|, the
     // two-step prefetch) falls outside it: the hot loop indexes it without clamping.
     int wd, pad, maxdb, maxcol, off_sel, off_cp, off_ct, off_b0, group_bytes, sel_len;
-    static constexpr int OFF_TBL = 0, OFF_COMB = 18 * 8, OFF_MISC = OFF_COMB + kTableMax * 4, OFF_LMAX = OFF_MISC + 16;
+    static constexpr int OFF_COMB = 0, OFF_MISC = OFF_COMB + kTableMax * 4, OFF_LMAX = OFF_MISC + 16;
     static constexpr int kBandHiPad = kBandRowSlack + 32;
     __host__ __device__ constexpr BandLayout(int c)   // c = band class
         : wd(128 << c), pad((128 << c) + (8 << c) + 8), maxdb(band_max_db(c)), maxcol(band_max_col(c)),
@@ -40,6 +40,13 @@ __host__ __device__ constexpr int max_band_wave_lds(int c) {
 }
 constexpr int kBandWaveLds = max_band_wave_lds(kNumBandClasses - 1);
 constexpr int kBandNeg16 = -20000;
+// Fixed symbol classes of the band kernels: what an alignment file's reads hold after wildcarding (call_locus.py:79):
+// A C G T, N, the wildcard X and '*' (any byte outside the alphabet).  v_perm selector = class index; a read with another
+// symbol (an IUPAC code) takes the exact kernels, whose classes are per read.  Row-word table: entries 0..17 by encoded
+// symbol (16 = '*', 17 = no row), then one entry per class for flank rows, which are staged as selector bytes.
+constexpr int kBandNClass = 7;
+constexpr int kBandTblClass0 = 18;
+__host__ __device__ constexpr int band_class_symbol(int c) { return c < 4 ? c : (c == 4 ? 15 /* X */ : (c == 5 ? 14 /* N */ : kStar)); }
 
 struct BandCtx {
     int lig;
@@ -192,7 +199,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
 // Processes 64/G items of band class BC (G = 8 << BC lanes per read), one per group.
 template <int BC>
 __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int4 q1, int4 q2, uint8_t* Lw, const uint8_t* s_enc,
-                                          const int8_t* s_mat) {
+                                          const uint8_t* s_sel, const uint2* s_tbl) {
     constexpr int g = kGap, G = 8 << BC;
     constexpr bool FLY = band_class_fly(BC);
     constexpr BandLayout lay(BC);
@@ -204,7 +211,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     const int grp = lane / G;
     const bool first = lig == 0, last = lig == G - 1;
     uint8_t* const Lg = Lw + grp * lay.group_bytes;
-    uint2* const tbl = reinterpret_cast<uint2*>(Lg + BandLayout::OFF_TBL);
+    const uint2* const tbl = s_tbl;   // row words: the same for every read (fixed symbol classes, band_kernel_body)
     int* const comb = reinterpret_cast<int*>(Lg + BandLayout::OFF_COMB);
     int* const misc = reinterpret_cast<int*>(Lg + BandLayout::OFF_MISC);
     int* const lmaxA = reinterpret_cast<int*>(Lg + BandLayout::OFF_LMAX);   // wide classes only
@@ -231,13 +238,13 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     const bool dbBeg = a.end_flags & 1, dbEnd = a.end_flags & 2, cBeg = a.end_flags & 4, cEnd = a.end_flags & 8;
 
     STRK_PHASE(0);
-    // ---- stage: class-byte array with pads, symbol set, row words, row symbols ------------------
+    // ---- stage: selector bytes with pads (window byte -> fixed symbol class, one LDS look-up per byte), row symbols ----
     if (first) misc[0] = 0;
     wave_lds_sync();
     {
-        // window bytes -> symbols, a dword per lane and eight dwords in flight (the loop is bound by load latency);
-        // slots outside the window get 0xff
-        unsigned mask = 0;
+        // a dword per lane and eight dwords in flight (the loop is bound by load latency); slots outside the window
+        // get selector 0x0c (constant 0: inert in G-space); a byte outside the fixed classes sets bit 7
+        unsigned other = 0;
         const uint8_t* seq = a.seqs + soff;
         constexpr int ND = lay.sel_len / 4;
         unsigned* const selw = reinterpret_cast<unsigned*>(selb);
@@ -263,43 +270,33 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int d = d0 + u * G;
-                unsigned out = 0;
+                unsigned out = 0x0c0c0c0cu;
+                if (ok[u] == 0xfu) {
+                    out = (unsigned)s_sel[w[u] & 0xffu] | ((unsigned)s_sel[(w[u] >> 8) & 0xffu] << 8) |
+                          ((unsigned)s_sel[(w[u] >> 16) & 0xffu] << 16) | ((unsigned)s_sel[w[u] >> 24] << 24);
+                } else if (ok[u]) {
+                    out = 0;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    unsigned sym = 0xffu;
-                    if ((ok[u] >> b) & 1u) { sym = s_enc[(w[u] >> (8 * b)) & 0xffu]; mask |= 1u << sym; }
-                    out |= sym << (8 * b);
+                    for (int b = 0; b < 4; ++b)
+                        out |= (((ok[u] >> b) & 1u) ? (unsigned)s_sel[(w[u] >> (8 * b)) & 0xffu] : 0x0cu) << (8 * b);
                 }
+                other |= out;
                 if (d < ND) selw[d] = out;
             }
         }
         STRK_PHASE(6);
-        if (mask) atomicOr(reinterpret_cast<unsigned*>(&misc[0]), mask);
+        if (other & 0x80808080u) misc[0] = 1;
         for (int k = lig; k < m; k += G) motifL[k] = act ? s_enc[motif[k]] : (uint8_t)kNullSym;
     }
     wave_lds_sync();
     STRK_PHASE(1);
-    const unsigned symmask = (unsigned)misc[0];
-    bool fallback = act && __popc(symmask) > 8;   // more symbol classes than a v_perm word holds: exact path decides
-    for (int e = lig; e < 18; e += G) {
-        unsigned wlo = 0, whi = 0;
-        if (e < kNSym) {
-            int k = 0;
-            for (int s = 0; s < kNSym; ++s) {
-                if (!((symmask >> s) & 1u)) continue;
-                if (k < 8) {
-                    const unsigned b = (unsigned)(s_mat[e * kNSym + s] + kWBias) & 0xffu;
-                    if (k < 4) wlo |= b << (8 * k); else whi |= b << (8 * (k - 4));
-                }
-                ++k;
-            }
-        }
-        tbl[e] = make_uint2(wlo, whi);
-    }
+    const bool fallback = act && misc[0] != 0;   // a symbol outside the fixed classes (IUPAC code in a read): exact path decides
     for (int e = lig; e < kTableMax; e += G) { comb[e] = kNegInf; if (FLY) lmaxA[e] = kNegInf; }
     {
+        // row symbols index the row-word table: kBandTblClass0 + class for a flank base (its selector byte), the
+        // encoded symbol for a motif base
         if (FLY) {
-            for (int k = lig; k < 256; k += G) cp[k] = (uint8_t)(k < nfl ? selb[lay.pad + k] : kNullSym);
+            for (int k = lig; k < 256; k += G) cp[k] = (uint8_t)(k < nfl ? kBandTblClass0 + selb[lay.pad + k] : kNullSym);
         } else {
             const int lenP = rowsP + 2 * (G - 1) + 4;
             const int gstep = G % m;
@@ -308,7 +305,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
             for (int idx = lig; idx < lenP; idx += G) {
                 const int row = idx - (G - 1);
                 int sym = kNullSym;
-                if (row >= 0 && row < rowsP) sym = row < nfl ? selb[lay.pad + row] : motifL[ph];
+                if (row >= 0 && row < rowsP) sym = row < nfl ? kBandTblClass0 + selb[lay.pad + row] : motifL[ph];
                 cp[idx] = (uint8_t)sym;
                 ph += gstep;
                 if (ph >= m) ph -= m;
@@ -318,22 +315,11 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
         for (int idx = lig; idx < lenT; idx += G) {
             const int row = idx - (G - 1);
             int sym = kNullSym;
-            if (row >= 0 && row < rowsT) sym = selb[lay.pad + ndb - 1 - row];
+            if (row >= 0 && row < rowsT) sym = kBandTblClass0 + selb[lay.pad + ndb - 1 - row];
             ct[idx] = (uint8_t)sym;
         }
     }
     wave_lds_sync();
-    for (int wi = lig; wi < lay.sel_len / 4; wi += G) {   // symbols -> v_perm selector bytes
-        unsigned* const w = reinterpret_cast<unsigned*>(selb) + wi;
-        const unsigned v = *w;
-        unsigned o = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const unsigned sym = (v >> (8 * b)) & 0xffu;
-            o |= (sym < (unsigned)kNSym ? (unsigned)__popc(symmask & ((1u << sym) - 1u)) : 0x0cu) << (8 * b);
-        }
-        *w = o;
-    }
     for (int k = lig; k < lay.maxcol; k += G) b0col[k] = (short)kBandNeg16;
     wave_lds_sync();
     STRK_PHASE(2);
@@ -345,10 +331,10 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     const bool run = act && !fallback && geo.ok;
     const int nEff = run ? n : 0;
     // backward pass (reversed right flank x reversed window), then forward pass with the fork rows
-    band_pass<G, true, false>(x, ct, run ? rowsT : 0, geo.bdlo, dbEnd, cEnd, 0, 0, 1, geo.cmin, geo.ncol, comb, b0col, lmaxA);
+    band_pass<G, true, false>(x, ct, (run && !(a.dbg & 2)) ? rowsT : 0, geo.bdlo, dbEnd, cEnd, 0, 0, 1, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
     STRK_PHASE(3);
-    band_pass<G, false, FLY>(x, cp, run ? rowsP : 0, geo.dlo, dbBeg, cBeg, nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col, lmaxA);
+    band_pass<G, false, FLY>(x, cp, (run && !(a.dbg & 1)) ? rowsP : 0, geo.dlo, dbBeg, cBeg, (a.dbg & 8) ? 0 : nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
     STRK_PHASE(4);
     if (run) {
@@ -367,8 +353,8 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
         for (int k = lig; k < n; k += G) ubA[k] = band_ub(geo, nfl, ntr, nfr, m, lo + k, a.end_flags);
     wave_lds_sync();
     if (act && first) {
-        bool certified = false;
-        if (run) {
+        bool certified = (a.dbg & 4) != 0;
+        if (run && !(a.dbg & 4)) {
             SeenMask64 seen;
             auto ub = [&](int k) { return ubA[k]; };
             const CertResult cr = search_replay_cert(a.est_cn[r], a.step, a.lsr, a.max_iters, a.tie_last, comb, lo, n, seen, ub);
@@ -407,13 +393,33 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
     const int nA = min(a.counters[kCntClass0 + kBandClass0 + CA], a.list_stride);
     const int nB = min(a.counters[kCntClass0 + kBandClass0 + CB], a.list_stride);
     if (nA + nB <= 0) return;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * kBandWaveLds + kLdsSlack];
+    // the row-word table sits in front of the per-wave regions: a stale row symbol (any byte) indexes at most 255 * 8 bytes
+    // past its start, which is still inside this array
+    constexpr int kTblBytes = 256;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kTblBytes + 4 * kBandWaveLds + kLdsSlack];
     __shared__ uint8_t s_enc[256];
-    __shared__ int8_t s_mat[kNSym * kNSym + 3];
-    s_enc[threadIdx.x] = c_enc[threadIdx.x];
-    for (int i = threadIdx.x; i < kNSym * kNSym; i += 256) s_mat[i] = c_mat[i / kNSym][i % kNSym];
+    __shared__ uint8_t s_sel[256];
+    uint2* const s_tbl = reinterpret_cast<uint2*>(lds);
+    {
+        const unsigned sym = c_enc[threadIdx.x];
+        s_enc[threadIdx.x] = (uint8_t)sym;
+        unsigned cls = 0x80u;   // not one of the fixed classes
+        for (int c = 0; c < kBandNClass; ++c) if ((int)sym == band_class_symbol(c)) cls = (unsigned)c;
+        s_sel[threadIdx.x] = (uint8_t)cls;
+        if (threadIdx.x < kTblBytes / 8) {
+            const int e = threadIdx.x < kBandTblClass0 ? (int)threadIdx.x : band_class_symbol(min((int)threadIdx.x - kBandTblClass0, kBandNClass - 1));
+            unsigned wlo = 0, whi = 0;
+            if (e < kNSym && (int)threadIdx.x < kBandTblClass0 + kBandNClass) {
+                for (int k = 0; k < kBandNClass; ++k) {
+                    const unsigned b = (unsigned)(c_mat[e][band_class_symbol(k)] + kWBias) & 0xffu;
+                    if (k < 4) wlo |= b << (8 * k); else whi |= b << (8 * (k - 4));
+                }
+            }
+            s_tbl[threadIdx.x] = make_uint2(wlo, whi);
+        }
+    }
     __syncthreads();
-    uint8_t* const Lw = lds + (threadIdx.x >> 6) * kBandWaveLds;
+    uint8_t* const Lw = lds + kTblBytes + (threadIdx.x >> 6) * kBandWaveLds;
     constexpr int perA = 64 / (8 << CA), perB = 64 / (8 << CB);   // reads per wave
     const int chA = (nA + perA - 1) / perA, chB = (nB + perB - 1) / perB;
     const int lane = threadIdx.x & 63;
@@ -458,8 +464,8 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
         int4 n0 = make_int4(0, 0, 0, 0), n1 = n0, n2 = n0;
         const int g_n = fetch(cn, act_n, n0, n1, n2);
         const unsigned sink = touch(act_n, n0, n1, n2, g_n);
-        if (c < chA) band_wave<CA>(a, act, q0, q1, q2, Lw, s_enc, s_mat);
-        else band_wave<CB>(a, act, q0, q1, q2, Lw, s_enc, s_mat);
+        if (c < chA) band_wave<CA>(a, act, q0, q1, q2, Lw, s_enc, s_sel, s_tbl);
+        else band_wave<CB>(a, act, q0, q1, q2, Lw, s_enc, s_sel, s_tbl);
         // the touch load's destination register stays reserved until the load has certainly landed
         asm volatile("s_waitcnt vmcnt(0)" : : "v"(sink) : "memory");
         c = cn; act = act_n; q0 = n0; q1 = n1; q2 = n2;

@@ -99,6 +99,8 @@ struct KArgs {
     int32_t band_mode;    // 1: eligible reads go through k_dp_band first (strk_search.h, "Banded scoring")
     int32_t band_limit;   // only reads with index < band_limit are eligible (a context on probation tries the band on a sample)
     uint8_t* exact;       // [n_reads] 1: the read's table holds exact scores, 0: band lower bounds
+    int32_t dbg;          // profiling aid (env STRKIT_AMD_DBG, results are wrong when set): 1 no forward pass, 2 no backward
+                          //    pass, 4 no in-kernel search, 8 no fork rows
     int32_t ref_mode;     // 1: reference-side scoring (repeats.py:23-43): candidate = fl + motif*i only, the
                           //    table holds (score, end_query) pairs, end_flags must be STRK_DB_END_FREE
 };

@@ -135,7 +135,7 @@ struct BandGeo {
 // symbols on the fly (left flank <= 255 rows from LDS, then the motif with a running phase).
 constexpr int kNumBandClasses = 4;
 STRK_HD constexpr int band_class_G(int c) { return 8 << c; }
-STRK_HD constexpr int band_max_db(int c) { return c == 0 ? 384 : (c == 1 ? 1024 : (c == 2 ? 4096 : 12288)); }
+STRK_HD constexpr int band_max_db(int c) { return c == 0 ? 448 : (c == 1 ? 1024 : (c == 2 ? 4096 : 12288)); }
 STRK_HD constexpr int band_max_col(int c) { return c == 0 ? 320 : (c == 1 ? 512 : (c == 2 ? 1024 : 1536)); }
 STRK_HD constexpr bool band_class_fly(int c) { return c >= 2; }
 constexpr int kBandMaxFlank = 127;

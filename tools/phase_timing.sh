@@ -4,7 +4,7 @@
 set -e
 mkdir -p gpurun_out
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-unused-parameter -DSTRK_PHASE_TIMING \
-  -o gpurun_out/libstrkit_amd_phase.so strkit_amd/csrc/strk_api.hip
+  -o gpurun_out/libstrkit_amd_phase.so strkit_amd/csrc/strk_api.hip -lz -lpthread
 STRKIT_AMD_LIB=$PWD/gpurun_out/libstrkit_amd_phase.so python3 - <<'PY'
 import sys; sys.path.insert(0, ".")
 from strkit_amd.synth import make_config

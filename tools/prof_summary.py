@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 output of tools/prof_bench.sh: per-kernel launch statistics (both traces) and the PMC
+counters averaged per launch of each kernel.  usage: prof_summary.py gpurun_out/prof_<tag> [out.json]"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+out = {}
+
+
+def short(name):
+    n = name.split("(")[0]
+    return n.replace("strk::", "").replace("void ", "").strip()
+
+
+for trace in ("trace", "trace_p1"):
+    rows = defaultdict(list)
+    for f in glob.glob(os.path.join(root, trace, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            rows[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    tot = sum(sum(v) for v in rows.values()) or 1.0
+    out[trace] = {k: {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v), "total_ms": sum(v) / 1e3,
+                      "share": sum(v) / tot} for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1]))}
+pmc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out["pmc_per_launch"] = {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"launches": max(len(v) for v in cs.values())} for k, cs in pmc.items()}
+json.dump(out, open(sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "summary.json"), "w"), indent=1)
+for trace in ("trace", "trace_p1"):
+    print(f"== {trace} (us per launch) ==")
+    for k, v in out[trace].items():
+        if v["share"] > 0.002:
+            print(f"{k:28s} calls {v['calls']:5d} avg {v['avg_us']:10.1f} min {v['min_us']:10.1f} total_ms {v['total_ms']:9.2f} share {v['share']:.3f}")
+print("== PMC per launch ==")
+for k, cs in out["pmc_per_launch"].items():
+    if cs.get("SQ_INSTS_VALU", 0) > 1e5 or cs.get("FETCH_SIZE", 0) > 100:
+        print(k, {c: round(v, 1) for c, v in cs.items()})
