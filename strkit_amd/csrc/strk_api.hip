@@ -312,7 +312,7 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     } in_flight;
     HIP_TRY(hipEventRecord(c->ev[0], st));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
-    if (a.rhash) hipLaunchKernelGGL(k_hash, dim3((b->n_reads + 255) / 256), dim3(256), 0, st, a);
+    if (a.rhash) hipLaunchKernelGGL(k_hash, dim3((b->n_reads + 31) / 32), dim3(256), 0, st, a);   // eight lanes per read
     enqueue_scoring(c, a, 0, nullptr, b->n_reads, 0, st, true);
     hipLaunchKernelGGL(k_replay, dim3(b->n_loci), dim3(64), 0, st, a, rp);
     HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));

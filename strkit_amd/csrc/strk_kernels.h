@@ -150,24 +150,36 @@ __device__ __forceinline__ unsigned long long hash_mix(unsigned long long h, uns
     return h ^ (h >> 29);
 }
 
+// Eight lanes per read: lane s hashes the 8-byte words s, s + 8, ... of the window (coalesced 64-byte rows), the
+// partial hashes are folded in lane order with three DPP-free shuffles.  Equal reads give equal hashes; unequal
+// reads with equal hashes are told apart byte by byte in k_plan.
 __global__ void __launch_bounds__(256) k_hash(KArgs a) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_reads) return;
-    const uint8_t* p = a.seqs + a.seq_off[r];
-    const int len = (int)(a.seq_off[r + 1] - a.seq_off[r]);
-    unsigned long long h = 0xCBF29CE484222325ull;
-    int i = 0;
-    for (; i + 8 <= len; i += 8) {
-        unsigned long long v;
-        __builtin_memcpy(&v, p + i, 8);
-        h = hash_mix(h, v);
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = gid >> 3, sl = gid & 7;
+    const bool act = r < a.n_reads;
+    unsigned long long h = 0xCBF29CE484222325ull + (unsigned long long)sl;
+    if (act) {
+        const uint8_t* p = a.seqs + a.seq_off[r];
+        const int len = (int)(a.seq_off[r + 1] - a.seq_off[r]);
+        const int nw = (len + 7) >> 3;
+        for (int w = sl; w < nw; w += 8) {
+            unsigned long long v = 0;
+            const int i = w << 3;
+            if (i + 8 <= len) __builtin_memcpy(&v, p + i, 8);
+            else for (int k = 0; i + k < len; ++k) v |= (unsigned long long)p[i + k] << (8 * k);
+            h = hash_mix(h, v + 0x9E3779B97F4A7C15ull * (unsigned long long)(w + 1));
+        }
     }
-    unsigned long long tail = 0;
-    for (int k = 0; i + k < len; ++k) tail |= (unsigned long long)p[i + k] << (8 * k);
-    h = hash_mix(h, tail);
-    h = hash_mix(h, ((unsigned long long)(unsigned)a.nfl[r] << 32) | (unsigned)a.ntr[r]);
-    h = hash_mix(h, ((unsigned long long)(unsigned)a.nfr[r] << 32) | (unsigned)a.est_cn[r]);
-    a.rhash[r] = h;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {   // lanes 0..7 of a read are adjacent: fold (0,1) (2,3).. then pairs of pairs
+        const unsigned long long other = (unsigned long long)__shfl_down((long long)h, o, 8);
+        h = hash_mix(h, other);
+    }
+    if (act && sl == 0) {
+        h = hash_mix(h, ((unsigned long long)(unsigned)a.nfl[r] << 32) | (unsigned)a.ntr[r]);
+        h = hash_mix(h, ((unsigned long long)(unsigned)a.nfr[r] << 32) | (unsigned)a.est_cn[r]);
+        a.rhash[r] = h;
+    }
 }
 
 __device__ inline bool same_read(const KArgs& a, int r, int q) {

@@ -161,7 +161,9 @@ STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, 
     }
     if (cls < 0) return b;
     const int32_t wd = 128 << cls;
-    if ((int64_t)wd * 5 > (ndb + 1) * 4) return b;   // the band must drop at least a fifth of the columns
+    // (a band wider than the window covers the whole matrix: such short windows cost no more here than in the exact
+    // kernel and spare it a launch that only a handful of reads would use)
+    if (cls > 0 && (int64_t)wd * 5 > (ndb + 1) * 4) return b;   // a wide band must drop at least a fifth of the columns
     const int64_t extra = wd - (span_hi - span_lo + 1);
     b.ok = 1;
     b.cls = cls;

@@ -1,11 +1,10 @@
 #!/bin/bash
-# default bench under different persistent-grid sizes (STRKIT_AMD_DP_BLOCKS) and pipeline depths
-for cfg in "$@"; do
-  blocks=${cfg%%:*}; depth=${cfg##*:}
-  STRKIT_AMD_DP_BLOCKS=$blocks python bench.py --steps 200 --warmup 24 --no-cpu-baseline --pipeline $depth 2>&1 | tail -1 > /tmp/gs.json
-  python3 - "$blocks" "$depth" <<'PY'
-import sys, json
-j = json.load(open("/tmp/gs.json"))
-print("blocks", sys.argv[1], "depth", sys.argv[2], round(j["value"] / 1e6, 1), "M reads/s", round(j["ms_per_step"], 3), "ms")
-PY
+# pipelined bench with the default grids and with full-size DP grids (STRKIT_AMD_DP_BLOCKS), at two pipeline depths
+mkdir -p gpurun_out/sweep
+for p in 2 4; do
+  for blk in 0 512; do
+    STRKIT_AMD_DP_BLOCKS=$blk python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --pipeline $p > gpurun_out/sweep/b_${p}_${blk}.json 2>/dev/null
+    python -c "
+import json;d=json.load(open('gpurun_out/sweep/b_${p}_${blk}.json'));print('pipeline',$p,'blocks',$blk,d['value']/1e6,d['ms_per_step'])"
+  done
 done
