@@ -110,6 +110,40 @@ def pmc_summary(kernel: str) -> dict | None:
         return None
 
 
+def run_e2e(data: dict) -> dict:
+    """`python -m strkit_amd call` on files: alignment file (block-wise through its .bai) + reference + catalog -> per-read copy
+    numbers, every stage timed.  calling_s = everything but reading the files (reference side, read extraction, counting,
+    filtering); report_s = building the per-read report rows."""
+    import shutil
+    from strkit_amd.frontend import call_sample
+    paths = data["paths"]
+    warm = os.path.join(data["dir"], "warm.bed")
+    with open(paths["loci"]) as fh, open(warm, "w") as out:
+        out.writelines(fh.readlines()[:200])
+    call_sample(paths["bam"], paths["ref"], warm)            # workspace allocation, library warm-up
+    t0 = time.perf_counter()
+    rep = call_sample(paths["bam"], paths["ref"], paths["loci"])
+    wall = time.perf_counter() - t0
+    st = rep["stage_times"]
+    truth = {(int(l), int(r)): int(c) for l, r, c in data["truth"]}
+    n_reads = n_true = 0
+    for row in rep["results"]:
+        for name, rd in row.get("reads", {}).items():
+            l, r = name[1:].split("_r")
+            n_reads += 1
+            n_true += rd["cn"] == truth[(int(l), int(r))]
+    calling = sum(st.get(k, 0.0) for k in ("ref_side_s", "realign_s", "extract_s", "count_s"))
+    out = {"loci": len(rep["results"]), "reads": n_reads, "read_len": int(data.get("read_len", 0)) or None,
+           "bam_mb": os.path.getsize(paths["bam"]) >> 20, "wall_s": wall, "loci_per_s": len(rep["results"]) / wall,
+           "reads_per_s": n_reads / wall, "calling_s": calling, "stage_s": st,
+           "device_share_of_calling": (st.get("count_device_s", 0.0)) / max(calling, 1e-9),
+           "reads_with_true_allele_cn": n_true, "dataset_gen_s": data["gen_s"],
+           "note": "wall_s = open + index + FASTA + catalog + calling + report rows; load_s (BGZF inflate of the block's records, all "
+                   "cores) runs in a second thread and overlaps calling, load_wait_s is what the caller waited for it"}
+    shutil.rmtree(data["dir"], ignore_errors=True)
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +162,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the pipeline-1 and host-buffer (PCIe-inclusive) sub-results")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (self-test)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end sub-result (BAM + FASTA + BED -> per-read copy numbers)")
+    ap.add_argument("--e2e-loci", type=int, default=10000)
+    ap.add_argument("--e2e-depth", type=int, default=30)
+    ap.add_argument("--e2e-read-len", type=int, default=15000)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,6 +191,17 @@ def main() -> None:
             catalog = make_batches(a.config, n_loci, 1, 0, pool)[0]      # the same catalog on every rank
         else:
             batches = make_batches(a.config, n_loci, max(1, a.batches), rank, pool)
+    e2e_data = None
+    if rank == 0 and a.gpus == 1 and not a.no_e2e and not a.strong:
+        # files for the end-to-end sub-result: north_star's "10 000 loci x 30x HiFi reads genotyped end-to-end", ~15 kb reads
+        import tempfile
+        from strkit_amd.frontend.synth_large import make_dataset_large
+        e2e_dir = tempfile.mkdtemp(prefix="strk_e2e_")
+        t_gen = time.perf_counter()
+        e2e_data = make_dataset_large(e2e_dir, n_loci=a.e2e_loci, depth=a.e2e_depth, read_len=a.e2e_read_len, seed=11, procs=cores)
+        e2e_data["gen_s"] = time.perf_counter() - t_gen
+        e2e_data["dir"] = e2e_dir
+        e2e_data["read_len"] = a.e2e_read_len
 
     import torch
     import torch.distributed as dist
@@ -320,6 +369,8 @@ def main() -> None:
         extras["h2d_inclusive"] = {"value": r2 / e2, "unit": "reads/s", "ms_per_step": e2 / nh * 1e3, "steps": nh,
                                    "note": "strk_count_loci with pageable host buffers in and out, one call at a time "
                                            "(PCIe + staging copies inside the step); never the headline value"}
+    if e2e_data is not None:
+        extras["e2e"] = run_e2e(e2e_data)
     fence()
 
     strong_check = None

@@ -215,10 +215,28 @@ int strk_realign(strk_ctx* ctx, int32_t n_pairs, const uint8_t* s1, const int64_
 int64_t strk_bam_scan(const uint8_t* buf, int64_t n_bytes, int64_t first_rec, int64_t cap, int64_t* rec_off, int32_t* tid,
                       int32_t* pos, int32_t* end, int32_t* flag, int32_t* l_seq, int32_t* clip_l, int32_t* clip_r);
 
+/* strk_bam_scan_piece: strk_bam_scan over a PIECE of the decompressed stream (block-wise access): a record cut off at the
+ * end of the piece is not an error; *end_off = offset just past the last complete record (where the next piece resumes). */
+int64_t strk_bam_scan_piece(const uint8_t* buf, int64_t n_bytes, int64_t first_rec, int64_t cap, int64_t* rec_off, int32_t* tid,
+                            int32_t* pos, int32_t* end, int32_t* flag, int32_t* l_seq, int32_t* clip_l, int32_t* clip_r,
+                            int64_t* end_off);
+
+/* strk_bam_names: the read names of n records (without their terminating NUL), concatenated; out_off is [n + 1].
+ * out == NULL: size query.  Returns the total length or a negative STRK_E_* code. */
+int64_t strk_bam_names(const uint8_t* buf, int64_t n_bytes, int64_t n, const int64_t* rec_off, uint8_t* out, int64_t out_cap,
+                       int64_t* out_off);
+
 /* strk_bgzf_inflate: decompresses a whole BGZF stream (BAM, bgzipped FASTA) with n_threads host threads (0 = all
  * cores); blocks are independent deflate streams, every block's CRC is checked.  out == NULL: returns the decompressed
  * size.  Otherwise returns the number of bytes written, or a negative STRK_E_* code. */
 int64_t strk_bgzf_inflate(const uint8_t* comp, int64_t n_comp, uint8_t* out, int64_t out_cap, int32_t n_threads);
+
+/* strk_bgzf_inflate_range: block-wise access (what an index such as .bai points into): inflates the consecutive BGZF blocks
+ * that start at compressed offset `coff` for as long as whole blocks fit into out_cap bytes; *next_coff = compressed offset
+ * of the first block NOT inflated (n_comp at the end of the file).  Returns the bytes written or a negative STRK_E_* code.
+ * A BAM virtual offset is (coff << 16 | offset inside the inflated block). */
+int64_t strk_bgzf_inflate_range(const uint8_t* comp, int64_t n_comp, int64_t coff, uint8_t* out, int64_t out_cap,
+                                int64_t* next_coff, int32_t n_threads);
 
 /* strk_extract_reads: item i = (record at rec_off[i], locus boundaries coords[4i..4i+3] = left_flank_coord, left_coord,
  * right_coord, right_flank_coord).  An item with alt_cigar_off[i+1] > alt_cigar_off[i] uses that CIGAR (BAM encoding)

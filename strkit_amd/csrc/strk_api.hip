@@ -20,6 +20,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <sched.h>
 #include <unistd.h>
 
 #include "../../include/strkit_amd.h"
@@ -47,6 +48,14 @@ std::atomic<int> g_calls_in_flight{0};
 // a level down.
 std::atomic<int> g_win_level{1};
 std::atomic<int> g_win_quiet{0};
+
+// CPUs this process may run on (a container's share, not the machine's core count)
+int host_cpus() {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) return CPU_COUNT(&set);
+    return std::max(1u, std::thread::hardware_concurrency());
+}
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -728,14 +737,18 @@ int strk_ref_repeat_count_batch(strk_ctx* ctx, int32_t n_loci, const int32_t* st
 }
 
 // ---- host-side front end (no device work, no context) -------------------------------------------------------------
-int64_t strk_bam_scan(const uint8_t* buf, int64_t n_bytes, int64_t first_rec, int64_t cap, int64_t* rec_off, int32_t* tid,
-                      int32_t* pos, int32_t* end, int32_t* flag, int32_t* l_seq, int32_t* clip_l, int32_t* clip_r) {
+static int64_t bam_scan_impl(const uint8_t* buf, int64_t n_bytes, int64_t first_rec, int64_t cap, int64_t* rec_off, int32_t* tid,
+                             int32_t* pos, int32_t* end, int32_t* flag, int32_t* l_seq, int32_t* clip_l, int32_t* clip_r, int64_t* end_off) {
     if (!buf || n_bytes < 0 || first_rec < 0 || cap < 0) return fail(STRK_E_INVALID, "bad argument");
     if (cap > 0 && (!rec_off || !tid || !pos || !end || !flag || !l_seq || !clip_l || !clip_r)) return fail(STRK_E_INVALID, "NULL output array");
     int64_t off = first_rec, n = 0;
     while (off + 4 <= n_bytes) {
         strk_fe::Rec r;
         int64_t next = 0;
+        if (end_off) {   // a piece of the stream: the last record may be cut off
+            const int32_t block = strk_fe::rd_i32(buf + off);
+            if (block >= 32 && off + 4 + block > n_bytes) break;
+        }
         if (!strk_fe::parse_rec(buf, n_bytes, off, &r, &next)) return fail(STRK_E_INVALID, "malformed BAM record at byte %lld", (long long)off);
         if (n < cap) {
             int64_t ref_len = 0;
@@ -752,7 +765,40 @@ int64_t strk_bam_scan(const uint8_t* buf, int64_t n_bytes, int64_t first_rec, in
         ++n;
         off = next;
     }
+    if (end_off) *end_off = off;
     return n;
+}
+
+int64_t strk_bam_scan(const uint8_t* buf, int64_t n_bytes, int64_t first_rec, int64_t cap, int64_t* rec_off, int32_t* tid,
+                      int32_t* pos, int32_t* end, int32_t* flag, int32_t* l_seq, int32_t* clip_l, int32_t* clip_r) {
+    return bam_scan_impl(buf, n_bytes, first_rec, cap, rec_off, tid, pos, end, flag, l_seq, clip_l, clip_r, nullptr);
+}
+
+int64_t strk_bam_scan_piece(const uint8_t* buf, int64_t n_bytes, int64_t first_rec, int64_t cap, int64_t* rec_off, int32_t* tid,
+                            int32_t* pos, int32_t* end, int32_t* flag, int32_t* l_seq, int32_t* clip_l, int32_t* clip_r,
+                            int64_t* end_off) {
+    if (!end_off) return fail(STRK_E_INVALID, "end_off is NULL");
+    return bam_scan_impl(buf, n_bytes, first_rec, cap, rec_off, tid, pos, end, flag, l_seq, clip_l, clip_r, end_off);
+}
+
+int64_t strk_bam_names(const uint8_t* buf, int64_t n_bytes, int64_t n, const int64_t* rec_off, uint8_t* out, int64_t out_cap,
+                       int64_t* out_off) {
+    if (!buf || n < 0 || (n > 0 && (!rec_off || !out_off))) return fail(STRK_E_INVALID, "bad argument");
+    int64_t w = 0;
+    if (out_off) out_off[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        strk_fe::Rec r;
+        int64_t next = 0;
+        if (!strk_fe::parse_rec(buf, n_bytes, rec_off[i], &r, &next)) return fail(STRK_E_INVALID, "malformed BAM record at byte %lld", (long long)rec_off[i]);
+        const int64_t len = r.l_name > 0 ? r.l_name - 1 : 0;
+        if (out) {
+            if (w + len > out_cap) return fail(STRK_E_NOMEM, "name buffer too small");
+            memcpy(out + w, r.name, (size_t)len);
+        }
+        w += len;
+        out_off[i + 1] = w;
+    }
+    return w;
 }
 
 int strk_extract_reads(const uint8_t* buf, int64_t n_bytes, int32_t n_items, const int64_t* rec_off, const int64_t* coords,
@@ -763,7 +809,9 @@ int strk_extract_reads(const uint8_t* buf, int64_t n_bytes, int32_t n_items, con
     if (n_items == 0) { if (seq_off) seq_off[0] = 0; return 0; }
     if (!buf || !rec_off || !coords || !status || !nfl || !ntr || !nfr || !seq_off) return fail(STRK_E_INVALID, "NULL argument");
     static const char kBases[] = "=ACMGRSVTWYHKDBN";
-    const int nt = n_items < 512 ? 1 : std::max(1, std::min<int>((int)std::thread::hardware_concurrency(), 32));
+    // one thread per thousand items: starting threads costs more than a few hundred items do, and a caller that loads the next
+    // block's records meanwhile (IndexedBam) needs the other cores
+    const int nt = std::max(1, std::min<int>({host_cpus(), 32, n_items / 1024}));
     auto parallel = [&](auto&& body) {   // body(first item, last item): contiguous slices, one per thread
         std::vector<std::thread> th;
         const int32_t per = (n_items + nt - 1) / nt;
@@ -831,6 +879,55 @@ int strk_extract_reads(const uint8_t* buf, int64_t n_bytes, int32_t n_items, con
     return 0;
 }
 
+int64_t strk_bgzf_inflate_range(const uint8_t* comp, int64_t n_comp, int64_t coff, uint8_t* out, int64_t out_cap,
+                                int64_t* next_coff, int32_t n_threads) {
+    if (!comp || !out || !next_coff || n_comp < 0 || coff < 0 || coff > n_comp || out_cap < 0) return fail(STRK_E_INVALID, "bad argument");
+    // walk the block headers from `coff` while the decompressed blocks still fit
+    std::vector<strk_fe::BgzfBlock> blocks;
+    int64_t off = coff, total = 0;
+    while (off < n_comp) {
+        std::vector<strk_fe::BgzfBlock> one;
+        int64_t sz = 0;
+        // the header of one block: reuse the indexer on a window that holds exactly this block
+        if (off + 18 > n_comp) return fail(STRK_E_INVALID, "truncated BGZF block header at byte %lld", (long long)off);
+        const uint8_t* p = comp + off;
+        if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return fail(STRK_E_INVALID, "not a BGZF block at byte %lld", (long long)off);
+        const int xlen = strk_fe::rd_u16(p + 10);
+        int bsize = -1;
+        for (int64_t x = 12; x + 4 <= 12 + xlen && off + x + 4 <= n_comp;) {
+            const int slen = strk_fe::rd_u16(p + x + 2);
+            if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2) bsize = strk_fe::rd_u16(p + x + 4);
+            x += 4 + slen;
+        }
+        if (bsize < 0 || off + bsize + 1 > n_comp) return fail(STRK_E_INVALID, "truncated BGZF block at byte %lld", (long long)off);
+        if (strk_fe::bgzf_index(p, bsize + 1, &one, &sz) || one.size() != 1) return fail(STRK_E_INVALID, "bad BGZF block at byte %lld", (long long)off);
+        if (total + one[0].out_len > out_cap) break;
+        one[0].in_off += off;
+        one[0].out_off = total;
+        total += one[0].out_len;
+        blocks.push_back(one[0]);
+        off += bsize + 1;
+    }
+    *next_coff = off;
+    const int nt = std::max(1, std::min<int>(n_threads > 0 ? n_threads : host_cpus(), 32));
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(16);
+            if (i >= blocks.size()) return;
+            for (size_t k = i; k < std::min(blocks.size(), i + 16); ++k)
+                if (!strk_fe::bgzf_inflate_block(comp, blocks[k], out)) bad.store(1);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt && (size_t)t * 16 < blocks.size() + 16; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (bad.load()) return fail(STRK_E_INVALID, "corrupt BGZF block (inflate or CRC failed)");
+    return total;
+}
+
 int64_t strk_bgzf_inflate(const uint8_t* comp, int64_t n_comp, uint8_t* out, int64_t out_cap, int32_t n_threads) {
     if (!comp || n_comp < 0) return fail(STRK_E_INVALID, "bad argument");
     std::vector<strk_fe::BgzfBlock> blocks;
@@ -838,7 +935,7 @@ int64_t strk_bgzf_inflate(const uint8_t* comp, int64_t n_comp, uint8_t* out, int
     if (strk_fe::bgzf_index(comp, n_comp, &blocks, &total)) return fail(STRK_E_INVALID, "not a BGZF stream (or truncated)");
     if (!out) return total;   // size query
     if (out_cap < total) return fail(STRK_E_NOMEM, "output buffer too small (%lld < %lld)", (long long)out_cap, (long long)total);
-    const int nt = std::max(1, std::min<int>(n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency(), 32));
+    const int nt = std::max(1, std::min<int>(n_threads > 0 ? n_threads : host_cpus(), 32));
     std::atomic<size_t> next{0};
     std::atomic<int> bad{0};
     auto work = [&]() {

@@ -18,7 +18,7 @@ from .. import _lib
 from ..batch import MIN_READ_ALIGN_SCORE, count_loci, filter_reads
 from ..realign import _gate as realign_gate, realign_pairs, realign_reads
 from ..repeat_count_params import RepeatCountParams, get_reference_rc_params
-from ..repeats import get_ref_repeat_counts
+from ..repeats import get_ref_repeat_counts, get_ref_repeat_counts_packed
 from ..segment import calculate_seq_with_wildcards
 from ..synth import LocusBatch
 from .bam import BamFile, read_bam
@@ -26,7 +26,7 @@ from .extract import (LowMeanBaseQual, MIN_AVG_PHRED, get_read_coords_from_cigar
                       get_sequence_data_for_locus)
 from .fasta import Fasta
 from .loci import Locus, load_loci, parse_loci_bed, resolve_contig
-from .native import NativeBam, extract_reads, realign_cigar_to_read_alignment
+from .native import IndexedBam, NativeBam, extract_reads, realign_cigar_to_read_alignment
 
 __all__ = ["CallOptions", "call_sample", "call_locus", "call_blocks", "call_blocks_sharded", "deal_locus_blocks", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
 
@@ -69,7 +69,11 @@ def _ref_window(locus: Locus, ref: Fasta):
 
 def get_loci_with_ref_data(block: list[Locus], ref: Fasta, respect_ref: bool = False, context=None) -> list[dict | None]:
     """call_locus.py:736-835 for a block of loci: reference windows, reference copy numbers by the same counter (all
-    loci in one batched library call), boundaries widened by the offsets it found.  None per skipped locus."""
+    loci in one batched library call), boundaries widened by the offsets it found.  None per skipped locus.
+    With a `Fasta` the windows of all loci are gathered and handed over as packed arrays (no Python per locus before
+    the result records); any other reference object goes through its `fetch`."""
+    if isinstance(ref, Fasta) and len(block) > 1:
+        return _loci_with_ref_data_packed(block, ref, respect_ref, context)
     windows = [_ref_window(locus, ref) for locus in block]
     jobs, idx = [], []
     for i, (locus, w) in enumerate(zip(block, windows)):
@@ -91,11 +95,110 @@ def get_loci_with_ref_data(block: list[Locus], ref: Fasta, respect_ref: bool = F
     return out
 
 
+def _loci_with_ref_data_packed(block: list[Locus], ref: Fasta, respect_ref: bool, context) -> list[dict | None]:
+    n = len(block)
+    out: list[dict | None] = [None] * n
+    lc = np.array([l.left_coord for l in block], np.int64)
+    rc = np.array([l.right_coord for l in block], np.int64)
+    fs = np.array([l.flank_size for l in block], np.int64)
+    mlen = np.array([l.motif_size for l in block], np.int64)
+    lfc = np.maximum(0, lc - fs)
+    rfc = rc + fs
+    contig_of = [l.contig for l in block]
+    ok = np.zeros(n, bool)
+    clen = np.zeros(n, np.int64)
+    arrays = {}
+    for c in set(contig_of):
+        try:
+            arrays[c] = ref.array(c)
+        except KeyError:
+            arrays[c] = None                                   # "invalid region" (InvalidLocus)
+    for i, c in enumerate(contig_of):
+        clen[i] = len(arrays[c]) if arrays[c] is not None else -1
+    end = np.minimum(rfc + 1, clen)                            # Python slicing of the fetch (call_locus.py:772)
+    nfl = lc - lfc
+    nfr = (end - 1) - rc                                       # ref_total_seq[off_r:-1]
+    ok = (clen >= 0) & (lfc <= clen) & (nfl >= fs) & (nfr >= fs) & (rc > lc)       # "reference flank size too small"
+    idx = np.flatnonzero(ok)
+    if idx.size == 0:
+        return out
+    # gather [lfc, end - 1) of every live locus into one flat array (the trailing +1 base is only used by realign)
+    lens = (end - 1 - lfc)[idx]
+    seq_off = np.concatenate(([0], np.cumsum(lens)))
+    seqs = np.empty(int(seq_off[-1]), np.uint8)
+    by_contig: dict[str, list[int]] = {}
+    for k, i in enumerate(idx.tolist()):
+        by_contig.setdefault(contig_of[i], []).append(k)
+    for c, ks in by_contig.items():
+        ks = np.array(ks, np.int64)
+        ln = lens[ks]
+        src0 = lfc[idx[ks]]
+        owner = np.repeat(np.arange(len(ks)), ln)
+        within = np.arange(int(ln.sum())) - (np.cumsum(ln) - ln)[owner]
+        seqs[seq_off[ks][owner] + within] = arrays[c][src0[owner] + within]
+    nfl_i, ntr_i, nfr_i = nfl[idx], (rc - lc)[idx], nfr[idx]
+    # "reference has flanking N[...] sequence" (call_locus.py:786-787): only loci with an N next to the tract are looked at
+    n_code = (ord("N"), ord("n"))
+    tr0 = seq_off[:-1] + nfl_i
+    sus = np.flatnonzero(np.isin(seqs[tr0 - 1], n_code) | np.isin(seqs[np.minimum(tr0 + ntr_i, len(seqs) - 1)], n_code))
+    drop = set()
+    for k in sus.tolist():
+        i = int(idx[k])
+        m_ = int(mlen[i])
+        a0 = int(tr0[k])
+        fl_s = seqs[int(seq_off[k]):a0].tobytes().decode()
+        fr_s = seqs[a0 + int(ntr_i[k]):int(seq_off[k + 1])].tobytes().decode()
+        if fl_s.endswith("N" * m_) or fr_s.startswith("N" * m_):
+            drop.add(k)
+    if drop:
+        keep = np.array([k not in drop for k in range(len(idx))])
+        return _merge_kept(block, ref, respect_ref, context, idx[keep], out)
+    est = np.rint(ntr_i / mlen[idx]).astype(np.int64)           # round(len(ref_seq) / motif_size): half to even
+    # get_reference_rc_params (repeat_count_params.py:17-42)
+    max_iters = np.where(est >= 2000, 50, np.where(est >= 1000, 150, np.where(est >= 200, 200, DEFAULT_REF_MAX_ITERS)))
+    step = np.where(est >= 2000, 15, np.where(est >= 1000, 5, np.where(est >= 200, 3, 1)))
+    lsr = np.where(est >= 2000, 1, 3)
+    motifs = b"".join(block[i].motif.encode() for i in idx.tolist())
+    motif_off = np.concatenate(([0], np.cumsum(mlen[idx])))
+    o9 = get_ref_repeat_counts_packed(est, seqs, seq_off, nfl_i, ntr_i, nfr_i, np.frombuffer(motifs, np.uint8), motif_off,
+                                      ntr_i, max_iters, lsr, step, VCF_ANCHOR_SIZE, respect_ref, context)
+    text = seqs.tobytes().decode("ascii")
+    so = seq_off.tolist()
+    o9l = o9.tolist()
+    for k, i in enumerate(idx.tolist()):
+        locus = block[i]
+        cn, _sc, l_off, r_off, _n1, _n2, a, b, _c = o9l[k]
+        base = so[k]
+        total_end = so[k + 1]
+        arr = arrays[contig_of[i]]
+        e = int(end[i])
+        # the reference's ref_total_seq carries one more base (call_locus.py:770-772)
+        out[i] = {"ref_cn": cn, "ref_total_seq": text[base:total_end] + chr(arr[e - 1]),
+                  "ref_seq": text[base + a:base + a + b], "ref_left_flank_seq": text[base:base + a],
+                  "ref_right_flank_seq": text[base + a + b:total_end],
+                  "left_coord_adj": locus.left_coord if respect_ref else locus.left_coord - max(0, l_off),
+                  "right_coord_adj": locus.right_coord if respect_ref else locus.right_coord + max(0, r_off)}
+    return out
+
+
+def _merge_kept(block, ref, respect_ref, context, keep_idx, out):
+    """Rare path of the packed reference side: some loci were dropped after the gather (flanking N runs); the kept ones
+    are run again as their own block."""
+    sub = [block[int(i)] for i in keep_idx]
+    res = _loci_with_ref_data_packed(sub, ref, respect_ref, context) if len(sub) > 1 else get_loci_with_ref_data(sub, ref, respect_ref, context)
+    for i, r in zip(keep_idx.tolist(), res):
+        out[i] = r
+    return out
+
+
 def get_locus_with_ref_data(locus: Locus, ref: Fasta, respect_ref: bool = False, context=None) -> dict | None:
     return get_loci_with_ref_data([locus], ref, respect_ref, context)[0]
 
 
 def _distributed() -> bool:
+    import os
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and "torch" not in sys.modules:
+        return False                      # a plain run never pays for importing torch
     try:
         import torch.distributed as dist
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -125,7 +228,10 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
                 sample_id: str | None = None, ctx: _lib.Context | None = None, processes: int = 1,
                 rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE,
                 tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL) -> dict:
-    bam = NativeBam(bam) if isinstance(bam, str) else bam      # a path: records stay in the decompressed stream
+    if isinstance(bam, str):     # a path: block-wise access through the .bai index when there is one, else the whole stream
+        import os
+        has_index = os.path.exists(bam + ".bai") or os.path.exists(os.path.splitext(bam)[0] + ".bai")
+        bam = IndexedBam(bam) if has_index else NativeBam(bam)
     ref = Fasta(ref) if isinstance(ref, str) else ref
     t0 = time.perf_counter()
     opts = CallOptions(flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params, min_read_align_score, tie_rule, end_flags)
@@ -203,19 +309,35 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = Non
     re-run locus by locus so that only the locus that fails is lost; `stage times["errors"]` lists them."""
     opts = opts or CallOptions()
     ctx = ctx or _lib.default_context()
-    run_block = _call_block_native if isinstance(bam, NativeBam) else _call_block_python
+    native = isinstance(bam, (NativeBam, IndexedBam))
+    run_block = _call_block_native if native else _call_block_python
     results: list[dict] = []
     n_depth = 0
     tm = {"ref_side_s": 0.0, "realign_s": 0.0, "extract_s": 0.0, "count_s": 0.0, "errors": []}
 
-    def safe(block):
+    # reference side of ALL loci first, a few thousand per library call (each of its lock-step rounds is one device launch
+    # however many loci take part); a chunk that fails is left to the per-block path below, which isolates the locus
+    ref_cache: dict[int, dict | None] = {}
+    flat = [l for blk in blocks for l in blk]
+    t_a = time.perf_counter()
+    for c0 in range(0, len(flat), 4096):
+        chunk = flat[c0:c0 + 4096]
+        try:
+            for locus, rd in zip(chunk, get_loci_with_ref_data(chunk, ref, opts.respect_ref, ctx)):
+                ref_cache[id(locus)] = rd
+        except (_lib.StrkError, ValueError):
+            pass
+    tm["ref_side_s"] += time.perf_counter() - t_a
+
+    def safe(block, records):
         nonlocal n_depth
         try:
-            rows, n = run_block(block, bam, ref, opts, ctx, tm)
+            known = [ref_cache[id(l)] for l in block] if all(id(l) in ref_cache for l in block) else None
+            rows, n = run_block(block, records, ref, opts, ctx, tm, known)
         except _lib.StrkError as e:
             if len(block) > 1:
                 for locus in block:
-                    safe([locus])
+                    safe([locus], records)
                 return
             print(f"strkit_amd: {block[0].log_str()} - skipping locus: {e}", file=sys.stderr)
             tm["errors"].append({"locus_index": block[0].t_idx, "error": str(e)})
@@ -223,10 +345,43 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = Non
         results.extend(rows)
         n_depth += n
 
-    for block in blocks:
-        safe(block)
+    if isinstance(bam, IndexedBam):
+        # block-wise access: the records of block k + 1 are inflated (all host cores, outside the GIL) while block k is
+        # being called; memory holds two blocks' worth of the alignment file, never the file
+        from concurrent.futures import ThreadPoolExecutor
+        blocks = [b for blk in blocks for b in _one_contig_blocks(blk)]
+        tm["load_s"] = tm["load_wait_s"] = 0.0
+
+        def load(block):
+            t0 = time.perf_counter()
+            reg = bam.region(block[0].contig, min(l.left_flank_coord for l in block), max(l.right_flank_coord for l in block) + 1)
+            return reg, time.perf_counter() - t0
+
+        with ThreadPoolExecutor(1) as pool:
+            fut = pool.submit(load, blocks[0]) if blocks else None
+            for k, block in enumerate(blocks):
+                t0 = time.perf_counter()
+                records, dt = fut.result()
+                tm["load_wait_s"] += time.perf_counter() - t0
+                tm["load_s"] += dt
+                fut = pool.submit(load, blocks[k + 1]) if k + 1 < len(blocks) else None
+                safe(block, records)
+    else:
+        for block in blocks:
+            safe(block, bam)
     results.sort(key=lambda r: r["locus_index"])
     return results, n_depth, tm
+
+
+def _one_contig_blocks(block):
+    """A block as the loader builds it stays on one contig (loci.py:277-280); a hand-made one is split."""
+    out: list[list[Locus]] = []
+    for locus in block:
+        if out and out[-1][0].contig == locus.contig:
+            out[-1].append(locus)
+        else:
+            out.append([locus])
+    return out
 
 
 def _empty_counts(n_loci):
@@ -234,10 +389,14 @@ def _empty_counts(n_loci):
             {"sc": np.zeros(0), "keep": np.zeros(0, bool), "locus_ok": np.ones(n_loci, bool)})
 
 
-def _count(batch: LocusBatch, opts: CallOptions, ctx):
+def _count(batch: LocusBatch, opts: CallOptions, ctx, tm=None):
     if not batch.n_reads:
         return _empty_counts(batch.n_loci)
-    res = count_loci(batch, opts.rc_params, ctx=ctx, tie_rule=opts.tie_rule, end_flags=opts.end_flags)
+    out = count_loci(batch, opts.rc_params, ctx=ctx, tie_rule=opts.tie_rule, end_flags=opts.end_flags, with_stats=tm is not None)
+    res = out
+    if tm is not None and isinstance(out, tuple):
+        res, st = out
+        tm["count_device_s"] = tm.get("count_device_s", 0.0) + st["kernel_ms"] / 1e3      # HIP-event time of the device work
     return res, filter_reads(batch, res, opts.min_read_align_score)
 
 
@@ -254,7 +413,7 @@ def _locus_row(locus: Locus, rd: dict, reads: dict, opts: CallOptions) -> dict:
     return row
 
 
-def _call_block_python(block, bam: BamFile, ref: Fasta, opts: CallOptions, ctx, tm):
+def _call_block_python(block, bam: BamFile, ref: Fasta, opts: CallOptions, ctx, tm, ref_data=None):
     """One block through bam.py / extract.py (the readable statement of the front end): (rows, reads kept)."""
     flank_size = opts.flank_size
     results: list[dict] = []
@@ -262,7 +421,8 @@ def _call_block_python(block, bam: BamFile, ref: Fasta, opts: CallOptions, ctx, 
     prepared = []                     # (locus, ref data, [(segment, query_coords, ref_coords) ...])
     realign_jobs = []                 # (index into prepared, index of the segment)
     t_a = time.perf_counter()
-    ref_data = get_loci_with_ref_data(block, ref, opts.respect_ref, ctx)
+    if ref_data is None:
+        ref_data = get_loci_with_ref_data(block, ref, opts.respect_ref, ctx)
     tm["ref_side_s"] += time.perf_counter() - t_a
     for locus, rd in zip(block, ref_data):
         if rd is None:
@@ -333,38 +493,40 @@ def _call_block_python(block, bam: BamFile, ref: Fasta, opts: CallOptions, ctx, 
     return results, n_depth
 
 
-def _call_block_native(block, bam, ref: Fasta, opts: CallOptions, ctx, tm):
-    """One block over a NativeBam: ONE strk_extract_reads call cuts every read of every locus; Python only loops over
-    loci (fetch by numpy) and over the reads that end up in the report.  (rows, reads kept)"""
+def _call_block_native(block, bam, ref: Fasta, opts: CallOptions, ctx, tm, ref_data=None):
+    """One block over the records of a NativeBam / an IndexedBam region: no Python per read before the report.  The
+    overlapping records of all loci come from one vectorised interval query (`fetch_many`), ONE strk_extract_reads call
+    (all host cores) cuts every read of every locus, one device call counts them, numpy filters them; only the rows of
+    the report are built read by read (timed apart as report_s).  (rows, reads kept)"""
     flank_size = opts.flank_size
     results: list[dict] = []
-    n_depth = 0
     t_a = time.perf_counter()
-    ref_data = get_loci_with_ref_data(block, ref, opts.respect_ref, ctx)
+    if ref_data is None:
+        ref_data = get_loci_with_ref_data(block, ref, opts.respect_ref, ctx)
     tm["ref_side_s"] += time.perf_counter() - t_a
     t_a = time.perf_counter()
-    live, rec_parts, coord_parts, counts = [], [], [], []
-    for locus, rd in zip(block, ref_data):
-        if rd is None:
-            results.append(_locus_dict(locus))
-            continue
-        idx = bam.fetch_indices(locus.contig, locus.left_flank_coord, locus.right_flank_coord)[:opts.max_reads]
-        live.append((locus, rd))
-        rec_parts.append(idx)
-        coord_parts.append(np.tile(np.array([locus.left_flank_coord, rd["left_coord_adj"], rd["right_coord_adj"],
-                                             locus.right_flank_coord], np.int64), (len(idx), 1)))
-        counts.append(len(idx))
+    live = [(locus, rd) for locus, rd in zip(block, ref_data) if rd is not None]
+    results.extend(_locus_dict(locus) for locus, rd in zip(block, ref_data) if rd is None)
     if not live:
         return results, 0
-    rec = np.concatenate(rec_parts) if rec_parts else np.zeros(0, np.int64)
-    coords = np.concatenate(coord_parts) if coord_parts else np.zeros((0, 4), np.int64)
+    lfc = np.array([l.left_flank_coord for l, _ in live], np.int64)
+    rfc = np.array([l.right_flank_coord for l, _ in live], np.int64)
+    lca = np.array([rd["left_coord_adj"] for _, rd in live], np.int64)
+    rca = np.array([rd["right_coord_adj"] for _, rd in live], np.int64)
+    contigs = {l.contig for l, _ in live}
+    if len(contigs) == 1:
+        rec, counts = bam.fetch_many(live[0][0].contig, lfc, rfc, opts.max_reads)
+    else:                                    # a hand-made block that mixes contigs
+        parts = [bam.fetch_indices(l.contig, int(a), int(b))[:opts.max_reads] for (l, _), a, b in zip(live, lfc, rfc)]
+        rec = np.concatenate(parts) if parts else np.zeros(0, np.int64)
+        counts = np.array([len(x) for x in parts], np.int64)
     item_locus = np.repeat(np.arange(len(live)), counts)
+    coords = np.stack((lfc, lca, rca, rfc), axis=1)[item_locus]
     tm["extract_s"] += time.perf_counter() - t_a
     alt = None
     if opts.realign and rec.size:     # soft-clipped reads of the whole block in one device call (realign.py:75-154)
         t_a = time.perf_counter()
-        lf = np.array([l.left_flank_coord for l, _ in live], np.int64)[item_locus]
-        rf = np.array([l.right_flank_coord for l, _ in live], np.int64)[item_locus]
+        lf, rf = lfc[item_locus], rfc[item_locus]
         left = (bam.clip_l[rec] > 0) & (bam.pos[rec] >= lf) & (bam.pos[rec] <= rf)
         right = (bam.clip_r[rec] > 0) & (bam.end[rec] >= lf) & (bam.end[rec] <= rf)
         cand = np.nonzero(left | right)[0]
@@ -385,37 +547,45 @@ def _call_block_native(block, bam, ref: Fasta, opts: CallOptions, ctx, tm):
     ok = ex["status"] == 0
     n_ok_per_locus = np.bincount(item_locus[ok], minlength=len(live))
     motifs = [l.motif.encode() for l, _ in live]
-    m_per_item = np.array([len(m) for m in motifs], np.int64)[item_locus[ok]]
+    mlen = np.array([len(m) for m in motifs], np.int64)
     ntr_ok = ex["ntr"][ok]
     batch = LocusBatch(
         seqs=ex["seqs"], seq_off=np.concatenate(([0], ex["seq_off"][1:][ok])).astype(np.int64),
         nfl=ex["nfl"][ok], ntr=ntr_ok, nfr=ex["nfr"][ok],
-        est_cn=np.rint(ntr_ok / m_per_item).astype(np.int32),          # round(len(tr) / motif_size), half to even
+        est_cn=np.rint(ntr_ok / mlen[item_locus[ok]]).astype(np.int32),      # round(len(tr) / motif_size), half to even
         read_off=np.concatenate(([0], np.cumsum(n_ok_per_locus))).astype(np.int32),
         motifs=np.frombuffer(b"".join(motifs), np.uint8).copy(),
-        motif_off=np.concatenate(([0], np.cumsum([len(m) for m in motifs]))).astype(np.int32))
+        motif_off=np.concatenate(([0], np.cumsum(mlen))).astype(np.int32))
     tm["extract_s"] += time.perf_counter() - t_a
     t_a = time.perf_counter()
-    res, flt = _count(batch, opts, ctx)
+    res, flt = _count(batch, opts, ctx, tm)
     tm["count_s"] += time.perf_counter() - t_a
+    # ---- report rows (call_locus.py:1279-1288,1340-1352) ------------------------------------------------------------
     t_a = time.perf_counter()
     ok_items = np.nonzero(ok)[0]
+    read_locus = item_locus[ok]
+    keep = flt["keep"] & flt["locus_ok"][read_locus]
+    kept = np.nonzero(keep)[0]
+    n_kept = np.bincount(read_locus[kept], minlength=len(live))
+    kept_rec = rec[ok_items[kept]]
+    names = bam.names(kept_rec)
+    strands = np.where(bam.flag[kept_rec] & 16, "-", "+").tolist()
+    cns = res["cn"][kept].tolist()
+    scs = [None if x != x else x for x in flt["sc"][kept].tolist()]
+    sls = batch.ntr[kept].tolist()
+    ws = (1.0 / np.maximum(n_kept, 1))[read_locus[kept]].tolist()
+    realn = [bool(alt) and int(it) in alt for it in ok_items[kept]] if alt else None
+    first = np.concatenate(([0], np.cumsum(n_kept))).tolist()
     for li, (locus, rd) in enumerate(live):
-        r0, r1 = int(batch.read_off[li]), int(batch.read_off[li + 1])
-        kept = [r for r in range(r0, r1) if flt["keep"][r]]
-        reads = {}
-        for r in kept:
-            it = int(ok_items[r])
-            ri = int(rec[it])
-            sc = float(flt["sc"][r])
-            reads[bam.name(ri)] = {"s": bam.strand(ri), "cn": int(res["cn"][r]), "w": 1.0 / len(kept),
-                                   "sc": None if np.isnan(sc) else sc, "sl": int(batch.ntr[r]),
-                                   **({"realn": True} if alt and it in alt else {})}
-        row = _locus_row(locus, rd, reads if flt["locus_ok"][li] else {}, opts)
-        n_depth += len(row["reads"])
-        results.append(row)
-    tm["extract_s"] += time.perf_counter() - t_a
-    return results, n_depth
+        a, b = first[li], first[li + 1]
+        if realn is None:
+            reads = {names[k]: {"s": strands[k], "cn": cns[k], "w": ws[k], "sc": scs[k], "sl": sls[k]} for k in range(a, b)}
+        else:
+            reads = {names[k]: {"s": strands[k], "cn": cns[k], "w": ws[k], "sc": scs[k], "sl": sls[k],
+                                **({"realn": True} if realn[k] else {})} for k in range(a, b)}
+        results.append(_locus_row(locus, rd, reads, opts))
+    tm["report_s"] = tm.get("report_s", 0.0) + time.perf_counter() - t_a
+    return results, int(len(kept))
 
 
 def write_json(report: dict, path: str) -> None:

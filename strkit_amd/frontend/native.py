@@ -3,7 +3,9 @@ strk_extract_reads): the per-read work of the front end in C++, as the reference
 `extract.py` remain the readable statement of the same rules; tests/test_frontend.py compares the two."""
 from __future__ import annotations
 
+import ctypes as C
 import gzip
+import os
 import struct
 
 import numpy as np
@@ -12,7 +14,7 @@ from .. import _lib
 from .bam import AlignedSegment, real_cigar
 from .loci import resolve_contig
 
-__all__ = ["NativeBam", "extract_reads", "realign_cigar_to_read_alignment", "bgzf_read"]
+__all__ = ["NativeBam", "IndexedBam", "extract_reads", "realign_cigar_to_read_alignment", "bgzf_read"]
 
 _SEQ_LUT = np.frombuffer(b"=ACMGRSVTWYHKDBN", np.uint8)
 
@@ -32,46 +34,38 @@ def bgzf_read(path: str, threads: int = 0) -> np.ndarray:
     return out
 
 
-class NativeBam:
-    """Decompressed BAM stream + per-record arrays (one C pass); records are addressed by index."""
+class _Records:
+    """Per-record arrays over a decompressed stretch of a BAM stream (one C pass, strk_bam_scan[_piece]); records are
+    addressed by index.  Base of NativeBam (whole file) and of the regions an IndexedBam hands out."""
 
-    def __init__(self, path: str):
-        self.data = bgzf_read(path)
-        raw = self.data
-        if raw[:4].tobytes() != b"BAM\x01":
-            raise ValueError(f"{path}: not a BAM file")
-        l_text, = struct.unpack_from("<i", raw, 4)
-        self.header_text = raw[8:8 + l_text].tobytes().rstrip(b"\0").decode("utf-8", "replace")
-        off = 8 + l_text
-        n_ref, = struct.unpack_from("<i", raw, off)
-        off += 4
-        self.contigs: list[tuple[str, int]] = []
-        for _ in range(n_ref):
-            l_name, = struct.unpack_from("<i", raw, off)
-            name = raw[off + 4:off + 4 + l_name - 1].tobytes().decode()
-            l_ref, = struct.unpack_from("<i", raw, off + 4 + l_name)
-            self.contigs.append((name, l_ref))
-            off += 8 + l_name
-        L = _lib.load()
-        n = L.strk_bam_scan(raw.ctypes.data, raw.size, off, 0, *([None] * 8))
-        if n < 0:
-            _lib.check(int(n))
+    data: np.ndarray
+    contigs: list
+
+    def _set_arrays(self, n: int):
         self.n_records = int(n)
         self.rec_off = np.zeros(n, np.int64)
         a32 = lambda: np.zeros(n, np.int32)  # noqa: E731
         self.tid, self.pos, self.end, self.flag, self.l_seq, self.clip_l, self.clip_r = a32(), a32(), a32(), a32(), a32(), a32(), a32()
-        got = L.strk_bam_scan(raw.ctypes.data, raw.size, off, n, self.rec_off.ctypes.data, self.tid.ctypes.data,
-                              self.pos.ctypes.data, self.end.ctypes.data, self.flag.ctypes.data, self.l_seq.ctypes.data,
-                              self.clip_l.ctypes.data, self.clip_r.ctypes.data)
-        if got < 0:
-            _lib.check(int(got))
+
+    def _scan_ptrs(self):
+        return [a.ctypes.data for a in (self.rec_off, self.tid, self.pos, self.end, self.flag, self.l_seq, self.clip_l, self.clip_r)]
+
+    def _trim(self, n: int):
+        for k in ("rec_off", "tid", "pos", "end", "flag", "l_seq", "clip_l", "clip_r"):
+            setattr(self, k, getattr(self, k)[:n])
+        self.n_records = int(n)
+
+    def _build_index(self):
         # coordinate-sorted record indices per contig (mapped records only)
         self._by_contig: dict[str, tuple[np.ndarray, np.ndarray, np.ndarray]] = {}
         mapped = (self.flag & 4) == 0
-        for t, (name, _) in enumerate(self.contigs):
+        tids = np.unique(self.tid[mapped]) if self.n_records else []
+        for t in tids:
+            if t < 0 or t >= len(self.contigs):
+                continue
             idx = np.nonzero(mapped & (self.tid == t))[0]
             idx = idx[np.argsort(self.pos[idx], kind="stable")]
-            self._by_contig[name] = (self.pos[idx], self.end[idx], idx)
+            self._by_contig[self.contigs[int(t)][0]] = (self.pos[idx], self.end[idx], idx)
 
     @property
     def references(self) -> list[str]:
@@ -86,10 +80,56 @@ class NativeBam:
         hi = int(np.searchsorted(pos, end, side="left"))
         return idx[:hi][rend[:hi] > start]
 
+    def fetch_many(self, contig: str, starts: np.ndarray, ends: np.ndarray, max_reads: int) -> tuple[np.ndarray, np.ndarray]:
+        """fetch_indices for many intervals of one contig at once (no Python per interval): (record indices of all
+        intervals concatenated, number of records per interval), at most `max_reads` per interval, coordinate order."""
+        starts, ends = np.asarray(starts, np.int64), np.asarray(ends, np.int64)
+        contig = resolve_contig(self._by_contig, contig)
+        if contig is None or len(starts) == 0:
+            return np.zeros(0, np.int64), np.zeros(len(starts), np.int64)
+        pos, rend, idx = self._by_contig[contig]
+        hi = np.searchsorted(pos, ends, side="left")
+        span = int((rend - pos).max()) if len(pos) else 0            # no record is longer than this on the reference
+        lo = np.searchsorted(pos, starts - span, side="left")
+        cnt = np.maximum(hi - lo, 0)
+        tot = int(cnt.sum())
+        owner = np.repeat(np.arange(len(starts)), cnt)
+        base = np.cumsum(cnt) - cnt
+        k = lo[owner] + (np.arange(tot) - base[owner])
+        keep = rend[k] > starts[owner]
+        owner, k = owner[keep], k[keep]
+        n_per = np.bincount(owner, minlength=len(starts))
+        if n_per.size and n_per.max() > max_reads:                   # "using the first max_reads" (call_locus.py:1056-1058)
+            first = np.cumsum(n_per) - n_per
+            rank = np.arange(len(owner)) - first[owner]
+            sel = rank < max_reads
+            owner, k = owner[sel], k[sel]
+            n_per = np.minimum(n_per, max_reads)
+        return idx[k], n_per
+
     def name(self, i: int) -> str:
         o = int(self.rec_off[i]) + 4
         l_name = int(self.data[o + 8])
         return self.data[o + 32:o + 32 + l_name - 1].tobytes().decode()
+
+    def names(self, idx: np.ndarray) -> list[str]:
+        """Read names of many records (one library call)."""
+        n = int(len(idx))
+        if n == 0:
+            return []
+        L = _lib.load()
+        rec_off = np.ascontiguousarray(self.rec_off[idx], np.int64)
+        off = np.zeros(n + 1, np.int64)
+        tot = L.strk_bam_names(self.data.ctypes.data, self.data.size, n, rec_off.ctypes.data, None, 0, off.ctypes.data)
+        if tot < 0:
+            _lib.check(int(tot))
+        buf = np.empty(max(int(tot), 1), np.uint8)
+        tot = L.strk_bam_names(self.data.ctypes.data, self.data.size, n, rec_off.ctypes.data, buf.ctypes.data, buf.size, off.ctypes.data)
+        if tot < 0:
+            _lib.check(int(tot))
+        text = buf[:int(tot)].tobytes().decode()
+        o = off.tolist()
+        return [text[o[i]:o[i + 1]] for i in range(n)]
 
     def strand(self, i: int) -> str:
         return "-" if self.flag[i] & 16 else "+"
@@ -122,6 +162,164 @@ class NativeBam:
         left = (self.clip_l[idx] > 0) & (self.pos[idx] >= left_flank_coord) & (self.pos[idx] <= right_flank_coord)
         right = (self.clip_r[idx] > 0) & (self.end[idx] >= left_flank_coord) & (self.end[idx] <= right_flank_coord)
         return left | right
+
+
+def _parse_header(raw: np.ndarray) -> tuple[str, list[tuple[str, int]], int]:
+    """(header text, contigs, offset of the first alignment record) of a decompressed BAM stream (or its beginning)."""
+    if raw[:4].tobytes() != b"BAM\x01":
+        raise ValueError("not a BAM file")
+    l_text, = struct.unpack_from("<i", raw, 4)
+    text = raw[8:8 + l_text].tobytes().rstrip(b"\0").decode("utf-8", "replace")
+    off = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, off)
+    off += 4
+    contigs: list[tuple[str, int]] = []
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", raw, off)
+        name = raw[off + 4:off + 4 + l_name - 1].tobytes().decode()
+        l_ref, = struct.unpack_from("<i", raw, off + 4 + l_name)
+        contigs.append((name, l_ref))
+        off += 8 + l_name
+    return text, contigs, off
+
+
+class NativeBam(_Records):
+    """The whole decompressed BAM stream in memory (all cores inflate it) + per-record arrays."""
+
+    def __init__(self, path: str):
+        self.data = bgzf_read(path)
+        raw = self.data
+        try:
+            self.header_text, self.contigs, off = _parse_header(raw)
+        except ValueError:
+            raise ValueError(f"{path}: not a BAM file") from None
+        L = _lib.load()
+        n = L.strk_bam_scan(raw.ctypes.data, raw.size, off, 0, *([None] * 8))
+        if n < 0:
+            _lib.check(int(n))
+        self._set_arrays(int(n))
+        got = L.strk_bam_scan(raw.ctypes.data, raw.size, off, n, *self._scan_ptrs())
+        if got < 0:
+            _lib.check(int(got))
+        self._build_index()
+
+
+class _Region(_Records):
+    pass
+
+
+class IndexedBam:
+    """Block-wise access to a coordinate-sorted BAM through its .bai index (SAM specification §5.2), the way the reference's
+    reader fetches one block of loci at a time (call_sample.py:121): the compressed file is memory-mapped, `region()`
+    starts at the virtual offset the 16 kb linear index gives for the region's first window, inflates consecutive BGZF
+    blocks on all cores (strk_bgzf_inflate_range) and stops at the first record that starts past the region.  Memory
+    use is one region, not the file."""
+
+    def __init__(self, path: str, index: str | None = None):
+        self.path = path
+        self.comp = np.memmap(path, np.uint8, "r")
+        L = _lib.load()
+        head = np.empty(1 << 20, np.uint8)
+        nxt = C.c_int64(0)
+        while True:                              # the header may span several blocks
+            got = L.strk_bgzf_inflate_range(self.comp.ctypes.data, self.comp.size, 0, head.ctypes.data, head.size, C.byref(nxt), 1)
+            if got < 0:
+                _lib.check(int(got))
+            try:
+                self.header_text, self.contigs, self._first = _parse_header(head[:int(got)])
+                break
+            except (struct.error, IndexError, ValueError):
+                if nxt.value >= self.comp.size or head.size > (1 << 28):
+                    raise ValueError(f"{path}: not a BAM file") from None
+                head = np.empty(head.size * 4, np.uint8)
+        index = index or (path + ".bai" if os.path.exists(path + ".bai") else os.path.splitext(path)[0] + ".bai")
+        self._lin = self._read_bai(index, len(self.contigs))
+
+    @staticmethod
+    def _read_bai(path: str, n_contigs: int) -> list[np.ndarray]:
+        raw = np.fromfile(path, np.uint8)
+        if raw[:4].tobytes() != b"BAI\x01":
+            raise ValueError(f"{path}: not a BAI index")
+        n_ref, = struct.unpack_from("<i", raw, 4)
+        off = 8
+        lin = []
+        for _ in range(n_ref):
+            n_bin, = struct.unpack_from("<i", raw, off)
+            off += 4
+            for _b in range(n_bin):
+                _bin, n_chunk = struct.unpack_from("<Ii", raw, off)
+                off += 8 + 16 * n_chunk
+            n_intv, = struct.unpack_from("<i", raw, off)
+            off += 4
+            lin.append(raw[off:off + 8 * n_intv].view("<u8").astype(np.uint64))
+            off += 8 * n_intv
+        return lin
+
+    @property
+    def references(self) -> list[str]:
+        return [c for c, _ in self.contigs]
+
+    def region(self, contig: str, beg: int, end: int, threads: int = 0) -> _Region:
+        """The records that can overlap [beg, end) on `contig` (plus, possibly, a few in front of it)."""
+        L = _lib.load()
+        out = _Region()
+        out.contigs = self.contigs
+        names = self.references
+        name = resolve_contig(names, contig)
+        tid = names.index(name) if name is not None else -1
+        lin = self._lin[tid] if 0 <= tid < len(self._lin) else np.zeros(0, np.uint64)
+        w = max(0, int(beg)) >> 14
+        nz = np.flatnonzero(lin[w:]) if w < len(lin) else np.zeros(0, np.int64)
+        if tid < 0 or nz.size == 0:
+            out.data = np.zeros(16, np.uint8)
+            out._set_arrays(0)
+            out._build_index()
+            return out
+        voff = int(lin[w + int(nz[0])])
+        coff, scan_from = voff >> 16, voff & 0xFFFF
+        # a first guess of the bytes the region needs: its share of the compressed file (x 4 for compression), doubled
+        # whenever it turns out too small; every piece is scanned once (the scan resumes where the last one stopped)
+        glen = max(1, self.contigs[tid][1])
+        cap = int(min(1 << 31, max(16 << 20, 4.0 * self.comp.size * (end - beg + 40000) / glen)))
+        buf = np.empty(cap, np.uint8)
+        n = 0                                     # bytes of `buf` that are filled
+        parts = []
+        keys = ("rec_off", "tid", "pos", "end", "flag", "l_seq", "clip_l", "clip_r")
+        while True:
+            nxt = C.c_int64(0)
+            got = L.strk_bgzf_inflate_range(self.comp.ctypes.data, self.comp.size, coff, buf[n:].ctypes.data, buf.size - n, C.byref(nxt), int(threads))
+            if got < 0:
+                _lib.check(int(got))
+            n += int(got)
+            coff = nxt.value
+            guess = (n - scan_from) // 2048 + 1024      # long reads: records of kilobytes; short ones: scanned twice
+            while True:
+                piece = _Region()
+                piece._set_arrays(guess)
+                end_off = C.c_int64(0)
+                k = L.strk_bam_scan_piece(buf.ctypes.data, n, scan_from, piece.n_records, *piece._scan_ptrs(), C.byref(end_off))
+                if k < 0:
+                    _lib.check(int(k))
+                if k <= guess:
+                    break
+                guess = int(k)
+            piece._trim(int(k))
+            scan_from = int(end_off.value)
+            past = (piece.tid != tid) | (piece.pos >= end)
+            if past.any():
+                piece._trim(int(np.argmax(past)))
+            parts.append(piece)
+            if past.any() or coff >= self.comp.size:
+                break
+            if buf.size - n < (1 << 17):          # no further block fits: more room, then on
+                buf = np.concatenate((buf[:n], np.empty(buf.size, np.uint8)))
+        for k_ in keys:
+            setattr(out, k_, np.concatenate([getattr(p_, k_) for p_ in parts]))
+        out.n_records = int(len(out.rec_off))
+        last = int(out.rec_off[-1]) + 4 + int(struct.unpack_from("<i", buf, int(out.rec_off[-1]))[0]) if out.n_records else 0
+        out.data = buf[:max(last, 16)]
+        out._build_index()
+        return out
 
 
 def realign_cigar_to_read_alignment(cigar: np.ndarray) -> np.ndarray:

@@ -13,7 +13,7 @@ from functools import lru_cache
 from . import _lib
 from .repeat_count_params import RepeatCountParams
 
-__all__ = ["get_ref_repeat_counts", "get_repeat_count", "get_ref_repeat_count"]
+__all__ = ["get_ref_repeat_counts", "get_ref_repeat_counts_packed", "get_repeat_count", "get_ref_repeat_count"]
 
 
 def _get_repeat_count(start_count: int, tr_seq: str, flank_left_seq: str, flank_right_seq: str, motif: str,
@@ -136,3 +136,31 @@ def get_ref_repeat_counts(
         a, b = int(o[6]), int(o[7])
         res.append(((int(o[0]), int(o[1])), int(o[2]), int(o[3]), (int(o[4]), int(o[5])), (db[:a], db[a:a + b], db[a + b:])))
     return res
+
+
+def get_ref_repeat_counts_packed(start, seqs, seq_off, nfl, ntr, nfr, motifs, motif_off, ref_size, max_iters, lsr, step,
+                                 vcf_anchor_size: int, respect_coords: bool = False, context: "_lib.Context | None" = None):
+    """`get_ref_repeat_counts` on packed arrays (no Python object per locus): locus i owns ``seqs[seq_off[i]:seq_off[i+1]]``
+    laid out fl|tr|fr and ``motifs[motif_off[i]:motif_off[i+1]]``; everything else is one value per locus.  Returns the
+    int32 array ``out9[n, 9]`` of strk_ref_repeat_count_batch: cn, score, l_offset, r_offset, n_offset_scores,
+    n_iters_final, new fl / tr / fr lengths."""
+    import numpy as np
+    n = int(len(start))
+    out = np.zeros((n, 9), np.int32)
+    if n == 0:
+        return out
+    ctx = context or _lib.default_context()
+    i32 = lambda v: np.ascontiguousarray(v, np.int32)  # noqa: E731
+    start, nfl, ntr, nfr, ref_size, max_iters, lsr, step = (i32(v) for v in (start, nfl, ntr, nfr, ref_size, max_iters, lsr, step))
+    seqs = np.ascontiguousarray(seqs, np.uint8)
+    motifs = np.ascontiguousarray(motifs, np.uint8)
+    seq_off = np.ascontiguousarray(seq_off, np.int64)
+    motif_off = i32(motif_off)
+    rc = _lib.load().strk_ref_repeat_count_batch(
+        ctx.handle, n, start.ctypes.data, seqs.ctypes.data, seq_off.ctypes.data, nfl.ctypes.data, ntr.ctypes.data,
+        nfr.ctypes.data, motifs.ctypes.data, motif_off.ctypes.data, ref_size.ctypes.data, int(vcf_anchor_size),
+        max_iters.ctypes.data, lsr.ctypes.data, step.ctypes.data, int(respect_coords), out.ctypes.data)
+    if rc == _lib.STRK_E_EMPTY:
+        raise ValueError("max() arg is an empty sequence")
+    _lib.check(rc)
+    return out

@@ -331,9 +331,9 @@ def test_large_expansions_do_not_overflow_the_extraction_buffer(tmp_path, long_c
 
 
 def test_threaded_extraction_equals_the_serial_one(tmp_path):
-    """More than 512 items take the multi-threaded path of strk_extract_reads: same bytes as item-by-item calls."""
+    """More than two thousand items take the multi-threaded path of strk_extract_reads: same bytes as piecewise calls."""
     from strkit_amd.frontend import NativeBam, extract_reads
-    t = make_dataset(str(tmp_path), n_loci=40, reads_per_locus=20, read_len=1200, seed=12, sub=0.01, indel=0.01, low_qual=0.02)
+    t = make_dataset(str(tmp_path), n_loci=60, reads_per_locus=40, read_len=1000, seed=12, sub=0.01, indel=0.01, low_qual=0.02)
     nb = NativeBam(t["paths"]["bam"])
     (block,) = load_loci(t["paths"]["loci"])
     rec, coords = [], []
@@ -342,7 +342,7 @@ def test_threaded_extraction_equals_the_serial_one(tmp_path):
         rec.append(idx)
         coords.append(np.tile([locus.left_flank_coord, locus.left_coord, locus.right_coord, locus.right_flank_coord], (len(idx), 1)))
     rec, coords = np.concatenate(rec), np.concatenate(coords)
-    assert len(rec) > 700
+    assert len(rec) > 2100
     whole = extract_reads(nb, rec, coords, 70, 13)
     parts = [extract_reads(nb, rec[i:i + 100], coords[i:i + 100], 70, 13) for i in range(0, len(rec), 100)]
     assert np.array_equal(whole["seqs"], np.concatenate([p["seqs"] for p in parts]))
@@ -372,3 +372,51 @@ def test_report_diff_logic():
     assert "DIFFERENT" in format_diff(d)
     same = diff_reports(theirs, theirs)
     assert same["identical"] and same["diffs"] == [] and same["sc_compared"] == 2
+
+
+def test_indexed_bam_regions_equal_the_whole_file(tmp_path):
+    """Block-wise access through the .bai linear index (IndexedBam.region: virtual offset -> strk_bgzf_inflate_range ->
+    strk_bam_scan_piece) returns, for every block of loci, the records the whole-file reader finds."""
+    from strkit_amd.frontend import IndexedBam, NativeBam
+    from strkit_amd.frontend.synth_large import make_dataset_large
+    t = make_dataset_large(str(tmp_path), n_loci=90, depth=7, read_len=2500, seed=5, spacing=9000, procs=2)
+    nb, ib = NativeBam(t["paths"]["bam"]), IndexedBam(t["paths"]["bam"])
+    assert nb.n_records == t["n_reads"] == 630 and ib.references == nb.references == ["chr1"]
+    blocks = load_loci(t["paths"]["loci"], max_block_size=25)
+    assert len(blocks) == 4
+    seen = 0
+    for blk in blocks:
+        reg = ib.region("chr1", min(l.left_flank_coord for l in blk), max(l.right_flank_coord for l in blk) + 1)
+        assert reg.data.size < nb.data.size // 2                     # a region, not the file
+        starts = np.array([l.left_flank_coord for l in blk]); ends = np.array([l.right_flank_coord for l in blk])
+        rec, n_per = reg.fetch_many("chr1", starts, ends, 250)
+        want = [nb.fetch_indices("chr1", int(s), int(e)) for s, e in zip(starts, ends)]
+        assert n_per.tolist() == [len(w) for w in want]
+        assert reg.names(rec) == [nb.name(int(i)) for w in want for i in w]
+        k = 0
+        for w in want[::6]:
+            pass
+        for li, w in enumerate(want):
+            for i in w[:2]:
+                a, b = reg.segment(int(rec[k])), nb.segment(int(i))
+                assert (a.name, a.start, a.end, a.query_sequence) == (b.name, b.start, b.end, b.query_sequence) and np.array_equal(a.cigar, b.cigar)
+                k += 1
+            k += len(w) - min(2, len(w))
+        seen += int(n_per.sum())
+        capped, n_cap = reg.fetch_many("chr1", starts, ends, 3)
+        assert n_cap.max() == 3 and np.array_equal(capped[:3], rec[:3])
+    assert seen == 630
+    # an interval without reads, a contig the file does not have, the "1" spelling of "chr1"
+    assert ib.region("chr1", 10, 500).fetch_indices("chr1", 10, 500).size == 0
+    assert ib.region("chrNope", 0, 1000).n_records == 0
+    assert ib.region("1", int(starts[0]), int(ends[0])).n_records > 0
+    # truth: every read extracted from its region gives its allele's size estimate (HiFi error rates)
+    truth = {(int(a), int(b)): int(c) for a, b, c in t["truth"]}
+    reg = ib.region("chr1", blocks[0][0].left_flank_coord, blocks[0][-1].right_flank_coord + 1)
+    l0 = blocks[0][3]
+    idx = reg.fetch_indices("chr1", l0.left_flank_coord, l0.right_flank_coord)
+    from strkit_amd.frontend import extract_reads
+    ex = extract_reads(reg, idx, np.tile([l0.left_flank_coord, l0.left_coord, l0.right_coord, l0.right_flank_coord], (len(idx), 1)), 70, 13)
+    for k, name in enumerate(reg.names(idx)):
+        l_, r_ = name[1:].split("_r")
+        assert ex["status"][k] == 0 and abs(round(int(ex["ntr"][k]) / len(l0.motif)) - truth[(int(l_), int(r_))]) <= 1

@@ -145,3 +145,62 @@ def test_chr_prefix_is_normalised_between_catalog_and_files(gpu_ctx, tmp_path):
     assert rep["catalog"] == {"num_loci": 5, "num_loci_unknown_contig": 1}
     for a, b in zip(base["results"], rep["results"]):
         assert {**a, "contig": None} == {**b, "contig": None} and b["contig"] == other
+
+
+def test_packed_reference_side_equals_the_per_locus_path(gpu_ctx, tmp_path):
+    """get_loci_with_ref_data over a block (windows gathered as packed arrays, one library call) against one locus at a
+    time through Fasta.fetch strings — soft-masked lower case, a locus too close to the contig start / end (skipped:
+    "reference flank size too small"), a tract flanked by N (skipped), a tract that continues into its flank."""
+    from strkit_amd.frontend import Fasta
+    from strkit_amd.frontend.call import get_loci_with_ref_data
+    from strkit_amd.frontend.fasta import write_fasta
+    from strkit_amd.frontend.loci import Locus
+    rng = np.random.default_rng(8)
+    rnd = lambda n: "".join("ACGT"[i] for i in rng.integers(4, size=n))  # noqa: E731
+    pieces, loci, pos = [], [], 0
+    specs = [("CAG", 12, "plain"), ("AT", 30, "lower"), ("GGC", 9, "extend"), ("TTTA", 15, "nflank"), ("A", 25, "plain"),
+             ("CCG", 20, "lower"), ("AAG", 14, "plain")]
+    for k, (m, cn, kind) in enumerate(specs):
+        gap = rnd(30 if k == 0 else 400)                       # the first locus sits too close to the contig start
+        tract = m * cn
+        if kind == "lower":
+            gap, tract = gap[:-80] + gap[-80:].lower(), tract.lower()
+        if kind == "extend":
+            gap = gap[:-6] + m * 2                                # two more copies hide in the left flank
+        if kind == "nflank":
+            gap = gap[:-4] + "NNNN"
+        pieces += [gap, tract]
+        pos += len(gap)
+        loci.append(Locus(k + 1, f"l{k}", "chr1", pos, pos + len(tract), m, 70))
+        pos += len(tract)
+    pieces.append(rnd(40))                                     # ... and the last one too close to its end
+    write_fasta(str(tmp_path / "r.fa"), {"chr1": "".join(pieces), "chr2": rnd(500)})
+    ref = Fasta(str(tmp_path / "r.fa"))
+    loci.append(Locus(9, "other", "chr2", 200, 230, "AC", 70))
+    loci.append(Locus(10, "nowhere", "chrX", 200, 230, "AC", 70))
+    block = get_loci_with_ref_data(loci, ref, False, gpu_ctx)
+    single = [get_loci_with_ref_data([l], ref, False, gpu_ctx)[0] for l in loci]
+    assert block == single
+    assert [r is None for r in block] == [True, False, False, True, False, False, True, False, True]
+    assert block[2]["left_coord_adj"] == loci[2].left_coord - 6 and block[1]["ref_seq"] == "at" * 30
+    assert get_loci_with_ref_data(loci, ref, True, gpu_ctx) == [get_loci_with_ref_data([l], ref, True, gpu_ctx)[0] for l in loci]
+
+
+def test_indexed_and_whole_file_access_give_the_same_report(gpu_ctx, tmp_path):
+    from strkit_amd.frontend import IndexedBam, NativeBam
+    from strkit_amd.frontend.synth_large import make_dataset_large
+    t = make_dataset_large(str(tmp_path), n_loci=450, depth=9, read_len=3000, seed=9, spacing=9000, procs=4)
+    a = call_sample(NativeBam(t["paths"]["bam"]), t["paths"]["ref"], t["paths"]["loci"])
+    b = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"])          # a path with a .bai: IndexedBam
+    assert "load_s" in b["stage_times"] and "load_s" not in a["stage_times"]
+    assert a["results"] == b["results"] and len(a["results"]) == 450
+    truth = {(int(x), int(y)): int(z) for x, y, z in t["truth"]}
+    n = hit = 0
+    for row in b["results"]:
+        # (a random flank may continue the repeat by a copy: the boundary extension then counts it)
+        assert abs(row["ref_cn"] - int(t["ref_cn"][row["locus_index"] - 1])) <= 1
+        for name, rd in row["reads"].items():
+            l_, r_ = name[1:].split("_r")
+            n += 1
+            hit += rd["cn"] == truth[(int(l_), int(r_))]
+    assert n == 450 * 9 and hit > 0.95 * n
