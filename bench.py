@@ -207,7 +207,7 @@ def main() -> None:
     import torch.distributed as dist
     from strkit_amd import _lib
     from strkit_amd.batch import batch_struct, make_params
-    from strkit_amd.sharding import deal_blocks, select_loci
+    from strkit_amd.sharding import NF, deal_blocks, gathered_step_table, select_loci, share_sizes, step_rows
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -221,7 +221,7 @@ def main() -> None:
         shares = deal_blocks(catalog, world)
         mine, my_reads = select_loci(catalog, shares[rank])
         batches = [mine]
-        n_pad = max(int(sum(catalog.read_off[l + 1] - catalog.read_off[l] for l in s)) for s in shares)
+        n_pad = max(share_sizes(catalog, shares))
     L = _lib.load()
 
     def resident(b):
@@ -248,7 +248,6 @@ def main() -> None:
     # is being gathered) and ONE RCCL all-gather per G steps collects the fixed-size records on every rank (the
     # reference merges its workers' results once per contig, call_sample.py:195-197,420, not once per locus block).
     G = max(D, a.gather_every) if use_dist else D
-    NF = 5
     stage = torch.full((2, G * NF, rows), -1, dtype=torch.int32, device=dev)
     gathered = torch.zeros((world * G * NF, rows), dtype=torch.int32, device=dev) if use_dist else None
     if a.strong:
@@ -260,7 +259,7 @@ def main() -> None:
         return (i + i // D) % NB        # every context sees every batch
 
     def out_of(i):
-        return stage[(i // G) % 2, NF * (i % G):NF * (i % G) + NF]
+        return step_rows(stage[(i // G) % 2], i % G)
 
     acc = dict(dp_ms=0.0, band_ms=0.0, all_ms=0.0, misses=0, fallback=0, dedup=0, band=0, band_fb=0, n=0, reads=0, loci=0,
                band_bytes=0, exact_bytes=0, cells=0, windows=set())
@@ -378,14 +377,9 @@ def main() -> None:
         # the gathered table of the last step against this rank counting the WHOLE catalog alone, bit for bit
         j = last % G
         if use_dist:
-            g = gathered.view(world, G * NF, rows)[:, NF * j:NF * j + NF].cpu().numpy()
+            table = gathered_step_table(gathered.cpu().numpy(), world, G, j, catalog.n_reads)
         else:
-            g = out_last.cpu().numpy()[None]
-        table = np.full((4, catalog.n_reads), -(1 << 30), np.int32)
-        for w in range(g.shape[0]):
-            idx = g[w, 0]
-            ok = idx >= 0
-            table[:, idx[ok]] = g[w, 1:5][:, ok]
+            table = gathered_step_table(out_last.cpu().numpy(), 1, 1, 0, catalog.n_reads)
         _t, sb_all = resident(catalog)
         one = torch.zeros((4, catalog.n_reads), dtype=torch.int32, device=dev)
         _lib.check(L.strk_count_loci_device(ctxs[0].handle, C.byref(sb_all), C.byref(p), one[0].data_ptr(), one[1].data_ptr(),

@@ -249,7 +249,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
         return call_blocks(bl, bam, ref, opts, ctx)
 
     if _distributed():          # launched under torch.distributed (one rank per GPU): shard the blocks
-        results, n_depth, tm = call_blocks_sharded(blocks, run)
+        results, n_depth, tm = call_blocks_sharded(blocks, run, ref, respect_ref)
     else:
         results, n_depth, tm = run(blocks)
     errors = tm.pop("errors", [])
@@ -282,24 +282,112 @@ def deal_locus_blocks(blocks: list[list[Locus]], world: int) -> list[list[int]]:
     return [sorted(o) for o in owner]
 
 
-def call_blocks_sharded(blocks, call_fn) -> tuple[list[dict], int, dict]:
+_STAGE_KEYS = ("ref_side_s", "realign_s", "extract_s", "count_s", "count_device_s", "report_s", "load_s", "load_wait_s")
+_NAME_BYTES = 64          # fixed width of the read-name field of a gathered per-read record (longer names: the field grows)
+
+
+def _encode_rows(rows: list[dict], errors: list[dict]):
+    """Per-locus rows -> fixed-size records: loci int64[n, 6] = (locus_index, status, ref_cn, start_adj, end_adj, n reads)
+    with status 0 called / 1 skipped (no reference data) / 2 failed; reads int64[m, 5] = (locus_index, cn, sl, flags,
+    sc as float64 bits) with flags bit 0 reverse strand, bit 1 realigned, bit 2 sc is None; names uint8[m, W]."""
+    n_reads = sum(len(r.get("reads") or {}) for r in rows)
+    width = max([_NAME_BYTES] + [len(nm.encode()) for r in rows for nm in (r.get("reads") or {})])
+    loci = np.zeros((len(rows) + len(errors), 6), np.int64)
+    reads = np.zeros((n_reads, 5), np.int64)
+    names = np.zeros((n_reads, width), np.uint8)
+    k = 0
+    for i, r in enumerate(rows):
+        called = "ref_cn" in r
+        rd = r.get("reads") or {}
+        loci[i] = (r["locus_index"], 0 if called else 1, r.get("ref_cn", 0), r.get("start_adj", r["start"]), r.get("end_adj", r["end"]), len(rd))
+        for nm, x in rd.items():
+            b = nm.encode()
+            names[k, :len(b)] = np.frombuffer(b, np.uint8)
+            sc = x.get("sc")
+            reads[k] = (r["locus_index"], x["cn"], x.get("sl", 0), (x["s"] == "-") | (2 if x.get("realn") else 0) | (4 if sc is None else 0),
+                        np.float64(0.0 if sc is None else sc).view(np.int64))
+            k += 1
+    for i, e in enumerate(errors):
+        loci[len(rows) + i] = (e["locus_index"], 2, 0, 0, 0, 0)
+    return loci, reads, names
+
+
+def _decode_rows(loci_by_index: dict, ref: Fasta, respect_ref: bool, loci_t: np.ndarray, reads_t: np.ndarray, names_t: np.ndarray):
+    """The inverse of _encode_rows on the gathered tables: rows in catalog order and the failed loci.  The strings of a row
+    (reference tract, anchor) are cut from the reference again: get_ref_repeat_count only ever MOVES flank bases into the
+    tract (repeats.py:171-176), so the adjusted tract is reference[start_adj:end_adj]."""
+    order = np.argsort(reads_t[:, 0], kind="stable") if len(reads_t) else np.zeros(0, np.int64)
+    reads_t, names_t = reads_t[order], names_t[order]
+    first = np.searchsorted(reads_t[:, 0], loci_t[:, 0], side="left") if len(reads_t) else np.zeros(len(loci_t), np.int64)
+    rows, errors = [], []
+    for (idx, status, ref_cn, s_adj, e_adj, n_reads), a in sorted(zip(loci_t.tolist(), first.tolist())):
+        locus = loci_by_index[idx]
+        if status == 2:
+            errors.append({"locus_index": idx, "error": "failed on the rank that owned it (see that rank's log)"})
+            continue
+        if status == 1:
+            rows.append(_locus_dict(locus))
+            continue
+        reads = {}
+        for k in range(a, a + n_reads):
+            _li, cn, sl, flags, sc_bits = reads_t[k].tolist()
+            nm = names_t[k].tobytes().rstrip(b"\0").decode()
+            reads[nm] = {"s": "-" if flags & 1 else "+", "cn": cn, "w": 1.0 / n_reads,
+                         "sc": None if flags & 4 else float(np.int64(sc_bits).view(np.float64)), "sl": sl,
+                         **({"realn": True} if flags & 2 else {})}
+        rd = {"ref_cn": ref_cn, "left_coord_adj": s_adj, "right_coord_adj": e_adj,
+              "ref_seq": ref.fetch(locus.contig, s_adj, e_adj),
+              "ref_left_flank_seq": ref.fetch(locus.contig, max(0, s_adj - VCF_ANCHOR_SIZE), s_adj)}
+        rows.append(_locus_row(locus, rd, reads, CallOptions(respect_ref=respect_ref)))
+    return rows, errors
+
+
+def _gather_padded(t, dist, device):
+    """all_gather of a 2-D table whose first dimension differs between ranks: counts first, then ONE all_gather_into_tensor
+    of the tables padded to the largest (fixed-size records: strkit_amd/sharding.py)."""
+    import torch
+    world = dist.get_world_size()
+    n = torch.tensor([t.shape[0], t.shape[1]], dtype=torch.int64, device=device)
+    ns = torch.zeros(world * 2, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(ns, n)
+    ns = ns.cpu().numpy().reshape(world, 2)
+    rows, cols = int(ns[:, 0].max()), int(ns[:, 1].max())
+    pad = torch.zeros((max(rows, 1), max(cols, 1)), dtype=t.dtype, device=device)
+    pad[:t.shape[0], :t.shape[1]] = t.to(device)
+    out = torch.zeros((world * pad.shape[0], pad.shape[1]), dtype=t.dtype, device=device)
+    dist.all_gather_into_tensor(out, pad)
+    out = out.cpu().numpy().reshape(world, pad.shape[0], pad.shape[1])
+    return [out[w, :int(ns[w, 0])] for w in range(world)]
+
+
+def call_blocks_sharded(blocks, call_fn, ref: Fasta | None = None, respect_ref: bool = False) -> tuple[list[dict], int, dict]:
     """One process per GPU (`--processes N` of the reference <-> N ranks of a torch.distributed job): every rank calls
     its share of the locus blocks with `call_fn(blocks) -> (results, reads kept, stage times)` and all ranks get the
     merged results ordered by locus index, as the reference's ordered merge does (call_sample.py:195-197,420).
-    The only communication is this collection of per-locus results."""
+    The only communication is the collection of the results as FIXED-SIZE records — one per locus, one per read, the
+    read names as a fixed-width byte field — with all_gather_into_tensor (RCCL over xGMI on the GPU box, gloo in the CPU
+    tests); no pickled Python objects cross ranks."""
+    import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     mine = [blocks[k] for k in deal_locus_blocks(blocks, world)[rank]]
-    results, n_depth, tm = call_fn(mine) if mine else ([], 0, {})
-    gathered: list = [None] * world
-    dist.all_gather_object(gathered, (results, n_depth, tm))
-    merged = sorted((r for part, _, _ in gathered for r in part), key=lambda r: r["locus_index"])
-    stage = {"errors": sorted((e for _, _, t in gathered for e in t.get("errors", [])), key=lambda e: e["locus_index"])}
-    for _, _, t in gathered:
-        for k, v in t.items():
-            if k != "errors":
-                stage[k] = max(stage.get(k, 0.0), v)    # ranks run side by side: the slowest one counts
-    return merged, sum(n for _, n, _ in gathered), stage
+    results, _n_depth, tm = call_fn(mine) if mine else ([], 0, {})
+    loci_t, reads_t, names_t = _encode_rows(results, tm.get("errors", []))
+    g_loci = _gather_padded(torch.from_numpy(loci_t), dist, device)
+    g_reads = _gather_padded(torch.from_numpy(reads_t), dist, device)
+    g_names = _gather_padded(torch.from_numpy(names_t), dist, device)
+    width = max(x.shape[1] for x in g_names)
+    g_names = [np.pad(x, ((0, 0), (0, width - x.shape[1]))) for x in g_names]
+    stage_t = torch.tensor([[float(tm.get(k, 0.0)) for k in _STAGE_KEYS]], dtype=torch.float64)
+    g_stage = np.concatenate(_gather_padded(stage_t, dist, device))
+    by_index = {l.t_idx: l for blk in blocks for l in blk}
+    merged, errors = _decode_rows(by_index, ref, respect_ref, np.concatenate(g_loci), np.concatenate(g_reads), np.concatenate(g_names))
+    stage = {"errors": errors}
+    for k, v in zip(_STAGE_KEYS, g_stage.max(axis=0).tolist()):      # ranks run side by side: the slowest one counts
+        if v > 0 or k in tm:
+            stage[k] = v
+    return merged, sum(len(r.get("reads") or {}) for r in merged), stage
 
 
 def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = None, ctx=None):

@@ -16,10 +16,11 @@ import numpy as np
 
 from .synth import LocusBatch
 
-__all__ = ["BLOCK_LOCI", "deal_blocks", "select_loci", "count_loci_sharded"]
+__all__ = ["BLOCK_LOCI", "NF", "deal_blocks", "select_loci", "count_loci_sharded", "share_sizes", "step_rows", "gathered_step_table"]
 
 BLOCK_LOCI = 200  # strkit/call/loci.py:193
 FIELDS = ("cn", "score", "n_iters", "start")
+NF = 5   # rows of one step's fixed-size records: read index | cn | score | n_iters | start
 
 
 def _block_costs(b: LocusBatch, block: int) -> np.ndarray:
@@ -53,20 +54,31 @@ def deal_blocks(b: LocusBatch, world: int, block: int = BLOCK_LOCI) -> list[np.n
     return out
 
 
+def _ranges(starts: np.ndarray, lens: np.ndarray) -> np.ndarray:
+    """Concatenation of arange(starts[k], starts[k] + lens[k]) for all k, without a Python loop."""
+    lens = np.asarray(lens, np.int64)
+    tot = int(lens.sum())
+    if tot == 0:
+        return np.zeros(0, np.int64)
+    owner = np.repeat(np.arange(len(lens)), lens)
+    return np.asarray(starts, np.int64)[owner] + (np.arange(tot) - (np.cumsum(lens) - lens)[owner])
+
+
 def select_loci(b: LocusBatch, loci: np.ndarray) -> tuple[LocusBatch, np.ndarray]:
-    """Sub-batch holding `loci` (in the given order) and the global read index of each of its reads."""
-    read_idx = [np.arange(int(b.read_off[l]), int(b.read_off[l + 1])) for l in loci]
-    reads = np.concatenate(read_idx).astype(np.int64) if len(read_idx) else np.zeros(0, np.int64)
-    seqs = [b.seqs[int(b.seq_off[r]):int(b.seq_off[r + 1])] for r in reads]
-    motifs = [b.motifs[int(b.motif_off[l]):int(b.motif_off[l + 1])] for l in loci]
-    lens = (b.seq_off[reads + 1] - b.seq_off[reads]) if len(reads) else np.zeros(0, np.int64)
+    """Sub-batch holding `loci` (in the given order) and the global read index of each of its reads (vectorised: a
+    whole-genome catalog has millions of reads)."""
+    loci = np.asarray(loci, np.int64)
+    n_per = (b.read_off[loci + 1] - b.read_off[loci]).astype(np.int64) if len(loci) else np.zeros(0, np.int64)
+    reads = _ranges(b.read_off[loci], n_per) if len(loci) else np.zeros(0, np.int64)
+    lens = (b.seq_off[reads + 1] - b.seq_off[reads]).astype(np.int64) if len(reads) else np.zeros(0, np.int64)
+    mlens = (b.motif_off[loci + 1] - b.motif_off[loci]).astype(np.int64) if len(loci) else np.zeros(0, np.int64)
     sub = LocusBatch(
-        seqs=np.concatenate(seqs).astype(np.uint8) if seqs else np.zeros(0, np.uint8),
+        seqs=b.seqs[_ranges(b.seq_off[reads], lens)] if len(reads) else np.zeros(0, np.uint8),
         seq_off=np.concatenate([[0], np.cumsum(lens)]).astype(np.int64),
         nfl=b.nfl[reads], ntr=b.ntr[reads], nfr=b.nfr[reads], est_cn=b.est_cn[reads],
-        read_off=np.concatenate([[0], np.cumsum([len(x) for x in read_idx])]).astype(np.int32),
-        motifs=np.concatenate(motifs).astype(np.uint8) if motifs else np.zeros(0, np.uint8),
-        motif_off=np.concatenate([[0], np.cumsum([len(x) for x in motifs])]).astype(np.int32),
+        read_off=np.concatenate([[0], np.cumsum(n_per)]).astype(np.int32),
+        motifs=b.motifs[_ranges(b.motif_off[loci], mlens)] if len(loci) else np.zeros(0, np.uint8),
+        motif_off=np.concatenate([[0], np.cumsum(mlens)]).astype(np.int32),
         true_cn=None if b.true_cn is None else b.true_cn[reads])
     return sub, reads
 
@@ -84,7 +96,7 @@ def count_loci_sharded(b: LocusBatch, count_fn: Callable[[LocusBatch], dict], de
     sub, reads = select_loci(b, shares[rank])
     res = count_fn(sub) if sub.n_reads else {k: np.zeros(0, np.int32) for k in FIELDS}
     # fixed-size records {read_idx, cn, score, n_iters, start}, padded to the largest shard
-    n_max = max(int(sum(b.read_off[l + 1] - b.read_off[l] for l in s)) for s in shares)
+    n_max = max(share_sizes(b, shares))
     rec = np.full((5, max(n_max, 1)), -1, np.int32)
     rec[0, :len(reads)] = reads
     for i, k in enumerate(FIELDS):
@@ -102,3 +114,29 @@ def count_loci_sharded(b: LocusBatch, count_fn: Callable[[LocusBatch], dict], de
         for i, k in enumerate(FIELDS):
             out[k][idx[ok]] = g[w, i + 1][ok]
     return out
+
+
+# ---- the staging layout bench.py --strong uses (one all-gather per G steps) ---------------------------------------------
+# A rank's staging buffer of one gather round is int32[G * NF, rows]: step j of the round owns rows [NF*j, NF*j + NF) =
+# (global read index | cn | score | n_iters | start), `rows` = the largest share padded with read index -1.  The
+# all-gather concatenates the ranks' buffers along the first dimension.
+def share_sizes(b: LocusBatch, shares: list[np.ndarray]) -> list[int]:
+    """Reads per rank for the shares `deal_blocks` made."""
+    return [int((b.read_off[np.asarray(s, np.int64) + 1] - b.read_off[np.asarray(s, np.int64)]).sum()) if len(s) else 0 for s in shares]
+
+
+def step_rows(stage, j: int):
+    """The NF rows of step j inside a staging buffer (a view: torch tensor or numpy array)."""
+    return stage[NF * j:NF * j + NF]
+
+
+def gathered_step_table(gathered: np.ndarray, world: int, G: int, j: int, n_reads: int) -> np.ndarray:
+    """int32[4, n_reads] table (cn, score, n_iters, start by GLOBAL read index) of step j of a gathered round
+    (`gathered` = int32[world * G * NF, rows]); reads no rank reported keep -(1 << 30)."""
+    g = np.asarray(gathered).reshape(world, G * NF, -1)[:, NF * j:NF * j + NF]
+    table = np.full((4, n_reads), -(1 << 30), np.int32)
+    for w in range(world):
+        idx = g[w, 0]
+        ok = idx >= 0
+        table[:, idx[ok]] = g[w, 1:5][:, ok]
+    return table

@@ -186,25 +186,61 @@ def test_adjusted_score_and_read_filters_follow_the_callers_loop():
     assert (~got["locus_ok"]).any() and got["locus_ok"].any()
 
 
+def _fake_rows(mine, ref):
+    """Stands in for the device path in the CPU test: rows of the real shape with made-up read records."""
+    from strkit_amd.frontend.call import CallOptions, _locus_dict, _locus_row
+    rows, errors = [], []
+    for blk in mine:
+        for l in blk:
+            if l.t_idx % 7 == 3:
+                rows.append(_locus_dict(l))                    # a skipped locus (no reference data)
+                continue
+            if l.t_idx % 11 == 5:
+                errors.append({"locus_index": l.t_idx, "error": "boom"})
+                continue
+            s_adj, e_adj = l.left_coord - (l.t_idx % 3), l.right_coord + (l.t_idx % 2)
+            rd = {"ref_cn": 5 + l.t_idx, "left_coord_adj": s_adj, "right_coord_adj": e_adj, "ref_seq": ref.fetch(l.contig, s_adj, e_adj),
+                  "ref_left_flank_seq": ref.fetch(l.contig, s_adj - 5, s_adj)}
+            n = l.t_idx % 4
+            reads = {f"read_{l.t_idx}_{k}" + "x" * (70 if k == 2 else 0): {"s": "+-"[k % 2], "cn": l.t_idx + k, "w": 1.0 / n,
+                                                                       "sc": None if k == 1 else 1.5 + 0.125 * k, "sl": 30 + k,
+                                                                       **({"realn": True} if k == 3 else {})} for k in range(n)}
+            rows.append(_locus_row(l, rd, reads, CallOptions()))
+    return rows, sum(len(r.get("reads") or {}) for r in rows), {"count_s": 0.1, "errors": errors}
+
+
+def _gloo_blocks():
+    from strkit_amd.frontend.loci import Locus
+    return [[Locus(10 * k + i + 1, f"l{10 * k + i}", "chr1", 200 + 100 * (10 * k + i), 200 + 100 * (10 * k + i) + 6 * (1 + (k * 7 + i) % 9), "CAG")
+             for i in range(1 + k % 4)] for k in range(11)]
+
+
+class _Ref:
+    seq = "ACGTTGCA" * 2000
+
+    def fetch(self, contig, a, b):
+        return self.seq[a:b]
+
+
 def _gloo_call_worker(rank, world, port, q):
     import torch.distributed as dist
     from strkit_amd.frontend.call import call_blocks_sharded
-    from strkit_amd.frontend.loci import Locus
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    blocks = [[Locus(10 * k + i + 1, f"l{10 * k + i}", "chr1", 1000 * (10 * k + i), 1000 * (10 * k + i) + 30 * (1 + (k * 7 + i) % 9), "CAG")
-               for i in range(1 + k % 4)] for k in range(11)]
+    ref = _Ref()
 
-    def fake_call(mine):      # stands in for the device path: one record per locus, tagged with the rank that made it
-        return [{"locus_index": l.t_idx, "rank": rank} for blk in mine for l in blk], sum(len(b) for b in mine), {"count_s": 0.1 * (rank + 1)}
+    def fake_call(mine):
+        rows, n, tm = _fake_rows(mine, ref)
+        return rows, n, {**tm, "count_s": 0.1 * (rank + 1)}
 
-    merged, n, tm = call_blocks_sharded(blocks, fake_call)
-    q.put((rank, [r["locus_index"] for r in merged], sorted({r["rank"] for r in merged}), n, tm))
+    merged, n, tm = call_blocks_sharded(_gloo_blocks(), fake_call, ref)
+    q.put((rank, merged, n, tm))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_call_driver_shards_locus_blocks_over_two_ranks():
-    """world_size-2 gloo: blocks are dealt to ranks, every rank ends with all loci in catalog order."""
+    """world_size-2 gloo: blocks are dealt to ranks, fixed-size per-locus / per-read records (names as a fixed-width field)
+    are all-gathered, and every rank ends with the rows a single process builds, in catalog order."""
     import socket
 
     import torch.multiprocessing as mp
@@ -218,15 +254,66 @@ def test_call_driver_shards_locus_blocks_over_two_ranks():
     procs = [ctx.Process(target=_gloo_call_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in procs]
+    got = [q.get(timeout=60) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    n_loci = sum(1 + k % 4 for k in range(11))
-    for rank, order, ranks_seen, n, tm in got:
-        assert order == sorted(order) and len(order) == n_loci and ranks_seen == [0, 1] and n == n_loci
+    want_rows, want_n, want_tm = _fake_rows(_gloo_blocks(), _Ref())
+    want_rows.sort(key=lambda r: r["locus_index"])
+    assert any(len(nm) > 64 for r in want_rows for nm in (r.get("reads") or {}))       # a name longer than the default field
+    for rank, merged, n, tm in got:
+        assert merged == want_rows and n == want_n
+        assert [e["locus_index"] for e in tm["errors"]] == [e["locus_index"] for e in want_tm["errors"]] != []
         assert abs(tm["count_s"] - 0.2) < 1e-9
     blocks = [[Locus(i + 1, "x", "chr1", 0, 100 * (i + 1), "CAG")] for i in range(7)]
     shares = deal_locus_blocks(blocks, 3)
     assert sorted(k for s_ in shares for k in s_) == list(range(7)) and shares == deal_locus_blocks(blocks, 3)
     assert shares[0][-1] == 6     # the heaviest block goes to the first rank
+
+
+def _gloo_stage_worker(rank, world, port, q):
+    """The staging / gather layout of `bench.py --strong`, on CPU tensors over gloo (the oracle stands in for the GPU)."""
+    import torch
+    import torch.distributed as dist
+    from strkit_amd.sharding import NF, deal_blocks, gathered_step_table, select_loci, share_sizes, step_rows
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    catalog = make_config(2, n_loci=26)
+    shares = deal_blocks(catalog, world, block=3)
+    mine, my_reads = select_loci(catalog, shares[rank])
+    rows, G = max(share_sizes(catalog, shares)), 3
+    stage = torch.full((G * NF, rows), -1, dtype=torch.int32)
+    stage[0::NF, :len(my_reads)] = torch.from_numpy(my_reads.astype(np.int32))
+    res = oracle_count(mine)
+    for j in range(G):                                     # G steps of one round (the same share every step)
+        o = step_rows(stage, j)
+        for i, k in enumerate(("cn", "score", "n_iters", "start")):
+            o[1 + i, :mine.n_reads] = torch.from_numpy(res[k] + j * (k == "n_iters"))     # steps differ: the layout must not mix them
+    gathered = torch.zeros((world * G * NF, rows), dtype=torch.int32)
+    dist.all_gather_into_tensor(gathered, stage)
+    q.put((rank, [gathered_step_table(gathered.numpy(), world, G, j, catalog.n_reads).tolist() for j in range(G)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_strong_staging_layout_over_two_ranks():
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_stage_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = oracle_count(make_config(2, n_loci=26))
+    for rank in (0, 1):
+        for j in range(3):
+            t = np.array(got[rank][j], np.int32)
+            assert np.array_equal(t[0], exp["cn"]) and np.array_equal(t[1], exp["score"])
+            assert np.array_equal(t[2], exp["n_iters"] + j) and np.array_equal(t[3], exp["start"])
