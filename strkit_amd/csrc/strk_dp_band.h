@@ -26,7 +26,7 @@ struct BandLayout {
     static constexpr int kBandHiPad = kBandRowSlack + 32;
     __host__ __device__ constexpr BandLayout(int c)   // c = band class
         : wd(128 << c), pad((128 << c) + (8 << c) + 8), maxdb(band_max_db(c)), maxcol(band_max_col(c)),
-          off_sel(OFF_LMAX + (band_class_fly(c) ? kTableMax * 4 : 0)),
+          off_sel(OFF_LMAX + (band_class_lmax(c) ? kTableMax * 4 : 0)),
           off_cp(off_sel + ((band_max_db(c) + 2 * ((128 << c) + (8 << c) + 8) + kBandHiPad + 15) & ~15)),
           // forward row symbols: the whole prefix (classes 0, 1) or 256 flank + 256 motif symbols (2, 3)
           off_ct(off_cp + (band_class_fly(c) ? 512 : ((band_max_db(c) + kBandRowSlack + 2 * (8 << c) + 4 + 15) & ~15))),
@@ -62,7 +62,7 @@ struct BandCtx {
 // One banded pass over `nrows` rows.  BWD = false: forward pass (columns = db, left to right);
 // BWD = true: backward pass in reversed coordinates (columns = reversed db).  dlo_ is the first
 // diagonal of the band, topFree/leftFree the free-end flags of the top row / left column.
-template <int G, bool BWD, bool FLY>
+template <int G, bool BWD, bool FLY, bool LMAX>
 __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsym, int nrows, int dlo_, bool topFree,
                                           bool leftFree, int nEff, int fork0, int m, int cmin, int ncol, int* comb,
                                           short* b0col, int* lmaxA) {
@@ -96,7 +96,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     if (BWD) forkG = g * nrows;                        // the backward pass has one event: its last row
     int forkIdx = 0;
     const int gm = g * m;
-    // wide classes (FLY): running maximum of the last column over the in-band rows.  Right of column |db|
+    // classes of band_class_lmax: running maximum of the last column over the in-band rows.  Right of column |db|
     // the pads replicate G(r, |db|), so from row |db| - dhi on the last lane's slot 15 holds that value.
     int lastmax = kNegInf;
     const int grFirst = g * max(1, ncols - dhi_);
@@ -141,7 +141,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         }                                                                                          \
         DST[15] = max(max(upEdge, DST[14]), SRC[15] + (int)(w3 >> 24));                            \
         houtL = DST[15];                                                                           \
-        if (FLY && !BWD) lastmax = (gr + g >= grFirst) ? max(lastmax, houtL - (gr + g)) : lastmax;  \
+        if (LMAX && !BWD) lastmax = (gr + g >= grFirst) ? max(lastmax, houtL - (gr + g)) : lastmax; \
         sel[0] = __builtin_amdgcn_alignbyte(sel[1], sel[0], 1);                                    \
         sel[1] = __builtin_amdgcn_alignbyte(sel[2], sel[1], 1);                                    \
         sel[2] = __builtin_amdgcn_alignbyte(sel[3], sel[2], 1);                                    \
@@ -161,7 +161,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
                 _Pragma("unroll") for (int k = 0; k < 16; k += 2)                                  \
                     acc = max(max(acc, DST[k] + (int)bc[k]), DST[k + 1] + (int)bc[k + 1]);         \
                 atomicMax(&comb[forkIdx], acc);                                                    \
-                if (FLY && x.last) lmaxA[forkIdx] = lastmax;                                       \
+                if (LMAX && x.last) lmaxA[forkIdx] = lastmax;                                      \
                 ++forkIdx;                                                                         \
                 forkG = forkIdx < nEff ? forkG + gm : 0x7fffffff;                                  \
             }                                                                                      \
@@ -202,6 +202,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
                                           const uint8_t* s_sel, const uint2* s_tbl) {
     constexpr int g = kGap, G = 8 << BC;
     constexpr bool FLY = band_class_fly(BC);
+    constexpr bool LMAX = band_class_lmax(BC);
     constexpr BandLayout lay(BC);
     const int lane = threadIdx.x & 63;
 #ifdef STRK_PHASE_TIMING
@@ -214,7 +215,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     const uint2* const tbl = s_tbl;   // row words: the same for every read (fixed symbol classes, band_kernel_body)
     int* const comb = reinterpret_cast<int*>(Lg + BandLayout::OFF_COMB);
     int* const misc = reinterpret_cast<int*>(Lg + BandLayout::OFF_MISC);
-    int* const lmaxA = reinterpret_cast<int*>(Lg + BandLayout::OFF_LMAX);   // wide classes only
+    int* const lmaxA = reinterpret_cast<int*>(Lg + BandLayout::OFF_LMAX);   // classes of band_class_lmax only
     uint8_t* const selb = Lg + lay.off_sel;
     uint8_t* const cp = Lg + lay.off_cp;       // staged prefix rows, or (FLY) 256 flank + 256 motif symbols
     uint8_t* const ct = Lg + lay.off_ct;
@@ -291,7 +292,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     wave_lds_sync();
     STRK_PHASE(1);
     const bool fallback = act && misc[0] != 0;   // a symbol outside the fixed classes (IUPAC code in a read): exact path decides
-    for (int e = lig; e < kTableMax; e += G) { comb[e] = kNegInf; if (FLY) lmaxA[e] = kNegInf; }
+    for (int e = lig; e < kTableMax; e += G) { comb[e] = kNegInf; if (LMAX) lmaxA[e] = kNegInf; }
     {
         // row symbols index the row-word table: kBandTblClass0 + class for a flank base (its selector byte), the
         // encoded symbol for a motif base
@@ -331,17 +332,17 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     const bool run = act && !fallback && geo.ok;
     const int nEff = run ? n : 0;
     // backward pass (reversed right flank x reversed window), then forward pass with the fork rows
-    band_pass<G, true, false>(x, ct, (run && !(a.dbg & 2)) ? rowsT : 0, geo.bdlo, dbEnd, cEnd, 0, 0, 1, geo.cmin, geo.ncol, comb, b0col, lmaxA);
+    band_pass<G, true, false, false>(x, ct, (run && !(a.dbg & 2)) ? rowsT : 0, geo.bdlo, dbEnd, cEnd, 0, 0, 1, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
     STRK_PHASE(3);
-    band_pass<G, false, FLY>(x, cp, (run && !(a.dbg & 1)) ? rowsP : 0, geo.dlo, dbBeg, cBeg, (a.dbg & 8) ? 0 : nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col, lmaxA);
+    band_pass<G, false, FLY, LMAX>(x, cp, (run && !(a.dbg & 1)) ? rowsP : 0, geo.dlo, dbBeg, cBeg, (a.dbg & 8) ? 0 : nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
     STRK_PHASE(4);
     if (run) {
         for (int k = lig; k < n; k += G) {
             const int R = nfl + (lo + k) * m;
             int sc = max(comb[k], -(1 << 28)) - g * (R + nfr + ndb);
-            if (FLY && cEnd) sc = max(sc, max(lmaxA[k], -(1 << 28)) - g * ndb);   // ends in the last column, in band
+            if (LMAX && cEnd) sc = max(sc, max(lmaxA[k], -(1 << 28)) - g * ndb);   // ends in the last column, in band
             comb[k] = sc;
             a.table[a.tab_off[r] + k] = sc;
         }

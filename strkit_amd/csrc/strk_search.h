@@ -138,6 +138,9 @@ STRK_HD constexpr int band_class_G(int c) { return 8 << c; }
 STRK_HD constexpr int band_max_db(int c) { return c == 0 ? 448 : (c == 1 ? 1024 : (c == 2 ? 4096 : 12288)); }
 STRK_HD constexpr int band_max_col(int c) { return c == 0 ? 320 : (c == 1 ? 512 : (c == 2 ? 1024 : 1536)); }
 STRK_HD constexpr bool band_class_fly(int c) { return c >= 2; }
+// classes that track the running maximum of the last column (alignments that end there above the fork row): all but the
+// narrowest one, where the bound on those alignments never reaches a good read's score (motifs of up to ~9 bases)
+STRK_HD constexpr bool band_class_lmax(int c) { return c >= 1; }
 constexpr int kBandMaxFlank = 127;
 constexpr int kBandRowSlack = 96;    // prefix rows a band item may have beyond |db|
 
@@ -147,7 +150,10 @@ STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, 
     if (nfl < 1 || nfr < 1 || nfr > kBandMaxFlank || m < 1 || m > 256 || n < 1 || n > 32) return b;
     const int64_t e_lo = (int64_t)ntr - (int64_t)(lo + n - 1) * m, e_hi = (int64_t)ntr - (int64_t)lo * m;
     const int64_t span_lo = e_lo < 0 ? e_lo : 0, span_hi = e_hi > 0 ? e_hi : 0;
-    int64_t smin = ndb >> 6;   // slack on each side: the certificate needs ~half the score deficit of the read
+    // slack on each side: the certificate needs about half the score deficit of the read, and a HiFi read's deficit grows
+    // with its length (~0.3 % errors at 9-12 points each): |db| / 32 keeps the certificate failures of kilobase windows
+    // (long motifs, BASELINE config 4) at a few per cent
+    int64_t smin = ndb >> 5;
     if (smin < 12) smin = 12;
     const int64_t need = span_hi - span_lo + 1 + 2 * smin;
     const int64_t rows = (int64_t)nfl + (int64_t)(lo + n - 1) * m;
@@ -195,9 +201,9 @@ STRK_HD int32_t band_ub(const BandGeo& b, int32_t nfl, int32_t ntr, int32_t nfr,
     if (v > L) L = v;
     v = band_len_beyond_lo(nc, ndb, e - ((int64_t)b.bdlo + b.wd - 1) - 1);
     if (v > L) L = v;
-    // alignments that end in the last column at a row <= R_i (free candidate end): the wide classes track
-    // the in-band ones exactly (the rest leaves the band: first term), the short classes bound them all
-    if ((end_flags & 8) && !band_class_fly(b.cls)) { v = band_len_beyond_hi(nc, ndb, ndb - R); if (v > L) L = v; }
+    // alignments that end in the last column at a row <= R_i (free candidate end): the classes of band_class_lmax track
+    // the in-band ones exactly (the rest leaves the band: first term), the narrowest class bounds them all
+    if ((end_flags & 8) && !band_class_lmax(b.cls)) { v = band_len_beyond_hi(nc, ndb, ndb - R); if (v > L) L = v; }
     if (end_flags & 4) { v = band_len_beyond_lo(nc, ndb, -R - 1); if (v > L) L = v; }      // starts on the left edge below R_i
     return (int32_t)(2 * L);
 }

@@ -93,7 +93,11 @@ def test_config5_full_shape(gpu_ctx):
     assert b.n_reads == 48 * 40
     ndb = (b.nfl + b.ntr + b.nfr).astype(np.int64)
     assert ndb.max() > 8000 and ndb.min() < 1500
-    base, st = _count(b, gpu_ctx)
+    from strkit_amd import _lib
+    fresh = _lib.Context(0)          # the shared test context may have switched its band off after a noisy batch
+    _count(b, fresh)                 # (a new context tries the band on a sample of the reads first)
+    base, st = _count(b, fresh)
+    fresh.close()
     assert st["n_fallback"] == 0 and st["n_band_reads"] > b.n_reads // 2
     exact, st0 = _count(b, gpu_ctx, band=False)
     _assert_same(b, base, exact, "band vs exact kernels")
