@@ -14,6 +14,7 @@ def main(argv=None) -> int:
     c.add_argument("--ref", required=True)
     c.add_argument("--loci", required=True)
     c.add_argument("--json", default="-")
+    c.add_argument("--vcf", default=None, help="also write the loci as VCF (read-level fields; alleles come from allele calling)")
     c.add_argument("--flank-size", type=int, default=70)
     c.add_argument("--min-avg-phred", type=int, default=13)
     c.add_argument("--max-reads", type=int, default=250)
@@ -50,6 +51,10 @@ def main(argv=None) -> int:
         dist.destroy_process_group()
         if not rank0:
             return 0
+    if a.vcf:
+        from .frontend.fasta import Fasta
+        from .frontend.output import write_vcf
+        write_vcf(rep, a.vcf, Fasta(a.ref), a.sample_id)
     if a.json == "-":
         import json
         json.dump(rep, sys.stdout, indent=1)

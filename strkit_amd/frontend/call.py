@@ -27,6 +27,7 @@ from .extract import (LowMeanBaseQual, MIN_AVG_PHRED, get_read_coords_from_cigar
 from .fasta import Fasta
 from .loci import Locus, load_loci, parse_loci_bed, resolve_contig
 from .native import IndexedBam, NativeBam, extract_reads, realign_cigar_to_read_alignment
+from .output import read_weights
 
 __all__ = ["CallOptions", "call_sample", "call_locus", "call_blocks", "call_blocks_sharded", "deal_locus_blocks", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
 
@@ -288,12 +289,13 @@ _NAME_BYTES = 64          # fixed width of the read-name field of a gathered per
 
 def _encode_rows(rows: list[dict], errors: list[dict]):
     """Per-locus rows -> fixed-size records: loci int64[n, 6] = (locus_index, status, ref_cn, start_adj, end_adj, n reads)
-    with status 0 called / 1 skipped (no reference data) / 2 failed; reads int64[m, 5] = (locus_index, cn, sl, flags,
-    sc as float64 bits) with flags bit 0 reverse strand, bit 1 realigned, bit 2 sc is None; names uint8[m, W]."""
+    with status 0 called / 1 skipped (no reference data) / 2 failed; reads int64[m, 6] = (locus_index, cn, sl, flags,
+    sc as float64 bits, w as float64 bits) with flags bit 0 reverse strand, bit 1 realigned, bit 2 sc is None;
+    names uint8[m, W]."""
     n_reads = sum(len(r.get("reads") or {}) for r in rows)
     width = max([_NAME_BYTES] + [len(nm.encode()) for r in rows for nm in (r.get("reads") or {})])
     loci = np.zeros((len(rows) + len(errors), 6), np.int64)
-    reads = np.zeros((n_reads, 5), np.int64)
+    reads = np.zeros((n_reads, 6), np.int64)
     names = np.zeros((n_reads, width), np.uint8)
     k = 0
     for i, r in enumerate(rows):
@@ -305,7 +307,7 @@ def _encode_rows(rows: list[dict], errors: list[dict]):
             names[k, :len(b)] = np.frombuffer(b, np.uint8)
             sc = x.get("sc")
             reads[k] = (r["locus_index"], x["cn"], x.get("sl", 0), (x["s"] == "-") | (2 if x.get("realn") else 0) | (4 if sc is None else 0),
-                        np.float64(0.0 if sc is None else sc).view(np.int64))
+                        np.float64(0.0 if sc is None else sc).view(np.int64), np.float64(x["w"]).view(np.int64))
             k += 1
     for i, e in enumerate(errors):
         loci[len(rows) + i] = (e["locus_index"], 2, 0, 0, 0, 0)
@@ -330,9 +332,9 @@ def _decode_rows(loci_by_index: dict, ref: Fasta, respect_ref: bool, loci_t: np.
             continue
         reads = {}
         for k in range(a, a + n_reads):
-            _li, cn, sl, flags, sc_bits = reads_t[k].tolist()
+            _li, cn, sl, flags, sc_bits, w_bits = reads_t[k].tolist()
             nm = names_t[k].tobytes().rstrip(b"\0").decode()
-            reads[nm] = {"s": "-" if flags & 1 else "+", "cn": cn, "w": 1.0 / n_reads,
+            reads[nm] = {"s": "-" if flags & 1 else "+", "cn": cn, "w": float(np.int64(w_bits).view(np.float64)),
                          "sc": None if flags & 4 else float(np.int64(sc_bits).view(np.float64)), "sl": sl,
                          **({"realn": True} if flags & 2 else {})}
         rd = {"ref_cn": ref_cn, "left_coord_adj": s_adj, "right_coord_adj": e_adj,
@@ -570,10 +572,14 @@ def _call_block_python(block, bam: BamFile, ref: Fasta, opts: CallOptions, ctx, 
         r0, r1 = int(batch.read_off[li]), int(batch.read_off[li + 1])
         kept = [r for r in range(r0, r1) if flt["keep"][r]]
         reads = {}
+        # read weights (call_locus.py:1254-1259): from the lengths of ALL segments fetched for the locus
+        lens_sorted = np.sort(np.array([e[0].length for e in prepared[li][2]], np.int64))
+        tlwf = (batch.nfl[r0:r1] + batch.ntr[r0:r1] + batch.nfr[r0:r1]).astype(np.int64)
+        ws = read_weights(lens_sorted, tlwf)
         for r in kept:
             name, strand, realigned, sl = meta[li][r - r0]
             sc = float(flt["sc"][r])
-            reads[name] = {"s": strand, "cn": int(res["cn"][r]), "w": 1.0 / len(kept),
+            reads[name] = {"s": strand, "cn": int(res["cn"][r]), "w": float(ws[r - r0]),
                            "sc": None if np.isnan(sc) else sc, "sl": sl, **({"realn": True} if realigned else {})}
         row = _locus_row(locus, rd, reads if flt["locus_ok"][li] else {}, opts)
         n_depth += len(row["reads"])
@@ -661,7 +667,19 @@ def _call_block_native(block, bam, ref: Fasta, opts: CallOptions, ctx, tm, ref_d
     cns = res["cn"][kept].tolist()
     scs = [None if x != x else x for x in flt["sc"][kept].tolist()]
     sls = batch.ntr[kept].tolist()
-    ws = (1.0 / np.maximum(n_kept, 1))[read_locus[kept]].tolist()
+    # read weights (call_locus.py:1254-1259, output.read_weights) for all loci at once: the lengths of ALL records fetched
+    # for a locus, sorted inside the locus; L = mean length of those that could contain flank + tract + flank
+    big = np.int64(1) << 40
+    lens_all = bam.l_seq[rec].astype(np.int64)
+    order = np.lexsort((lens_all, item_locus))
+    key = item_locus[order] * big + lens_all[order]
+    csum = np.concatenate(([0], np.cumsum(lens_all[order])))
+    loc_end = np.cumsum(counts)                                   # end of each locus' run in `order`
+    tlwf = (batch.nfl[kept].astype(np.int64) + batch.ntr[kept] + batch.nfr[kept])
+    part = np.searchsorted(key, read_locus[kept] * big + tlwf, side="left")
+    e_ = loc_end[read_locus[kept]]
+    L = (csum[e_] - csum[part]) / np.maximum(e_ - part, 1)
+    ws = ((L + tlwf - 2.0) / (L - tlwf + 1.0)).tolist()
     realn = [bool(alt) and int(it) in alt for it in ok_items[kept]] if alt else None
     first = np.concatenate(([0], np.cumsum(n_kept))).tolist()
     for li, (locus, rd) in enumerate(live):

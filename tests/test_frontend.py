@@ -420,3 +420,51 @@ def test_indexed_bam_regions_equal_the_whole_file(tmp_path):
     for k, name in enumerate(reg.names(idx)):
         l_, r_ = name[1:].split("_r")
         assert ex["status"][k] == 0 and abs(round(int(ex["ntr"][k]) / len(l0.motif)) - truth[(int(l_), int(r_))]) <= 1
+
+
+def test_read_weights_reproduce_the_documented_example():
+    """docs/output_formats.md:92-104: a read whose tract has 31 bases (flank 70: 171 with flanks) carries w = 1.0217145751733625
+    in a sample of HiFi reads.  The formula of output.read_weights, (L + t - 2) / (L - t + 1), gives exactly that number for
+    one L (15 790.2), a plausible mean HiFi read length - the one anchor the reference's tree holds for this quantity."""
+    from strkit_amd.frontend.output import allele_calling_inputs, read_weights
+    w, t = 1.0217145751733625, 171.0
+    L = (t - 2 + w * (t - 1)) / (w - 1)
+    assert 15000 < L < 17000
+    assert abs(read_weights(np.array([L]), np.array([t]))[0] - w) < 1e-12
+    # partition: only reads long enough to contain flank + tract + flank enter the mean
+    lens = np.array([100, 200, 1000, 3000])
+    got = read_weights(lens, np.array([150, 250, 90, 5000]))
+    exp = [((200 + 1000 + 3000) / 3 + 148) / ((200 + 1000 + 3000) / 3 - 149), (2000 + 248) / (2000 - 249), (4300 / 4 + 88) / (4300 / 4 - 89)]
+    assert np.allclose(got[:3], exp) and np.isnan(got[3])
+    assert np.allclose(read_weights(lens, np.array([150.0]), read_length=np.array([900.0]), targeted=True), [(900 + 148) / (900 - 149)])
+    cns, wn = allele_calling_inputs({"reads": {"a": {"cn": 8, "w": 1.0}, "b": {"cn": 9, "w": 3.0}}})
+    assert cns.dtype == np.int32 and cns.tolist() == [8, 9] and wn.dtype == np.float64 and wn.tolist() == [0.25, 0.75]
+
+
+def test_mcrl_slr_and_vcf_rows(tmp_path):
+    from strkit_amd.frontend.output import mcrl_field, slr_field, write_vcf
+    # the example of output/vcf.py:320-321: two alleles with 8 and 9 copies -> 7x1|8x10|9x1 , 8x2|9x12
+    reads = {}
+    for p, hist in ((0, {7: 1, 8: 10, 9: 1}), (1, {8: 2, 9: 12})):
+        for cn, k in hist.items():
+            for i in range(k):
+                reads[f"r{p}_{cn}_{i}"] = {"s": "+", "cn": cn, "w": 1.0, "sc": 2.0, "sl": 3 * cn + (i == 0), "p": p}
+    assert mcrl_field(reads, 2) == ("7x1|8x10|9x1", "8x2|9x12")
+    assert slr_field(reads, 2) == ("21x0|22x1|24x9|25x1|27x0|28x1".replace("21x0|", "").replace("27x0|", ""), "24x1|25x1|27x11|28x1")
+    assert mcrl_field(reads) == ("7x1|8x12|9x13",)
+    rep = {"sample_id": "s1", "catalog": {"num_loci": 3}, "results": [
+        {"locus_index": 2, "locus_id": "HTT", "contig": "chr4", "start": 3074876, "end": 3074940, "start_adj": 3074874, "end_adj": 3074940,
+         "motif": "CAG", "ref_cn": 22, "ref_start_anchor": "ccatg", "ref_seq": "cag" * 22, "reads": reads, "call": [8, 9], "assign_method": "dist"},
+        {"locus_index": 1, "locus_id": "l1", "contig": "chr4", "start": 100, "end": 130, "motif": "AC", "ref_cn": 15,
+         "ref_start_anchor": "TTTTT", "ref_seq": "AC" * 15, "reads": {"x": {"s": "-", "cn": 15, "w": 1.0, "sc": 2.0, "sl": 30}}, "call": None},
+        {"locus_index": 3, "locus_id": "skipped", "contig": "chr4", "start": 500, "end": 530, "motif": "AC", "call": None}]}
+    path = str(tmp_path / "o.vcf")
+    assert write_vcf(rep, path, date="20261004") == 2
+    body = [l for l in open(path).read().splitlines() if not l.startswith("##")]
+    assert body[0].split("\t")[-1] == "s1" and len(body) == 3
+    f = body[1].split("\t")
+    assert f[:5] == ["chr4", "96", "l1", "TTTTT" + "AC" * 15, "."] and f[7] == "VT=str;MOTIF=AC;REFMC=15;BED_START=100;BED_END=130;ANCH=5"
+    assert f[8:] == ["GT:DP:MCRL:SLR", "./.:1:15x1:30x1"]
+    f = body[2].split("\t")
+    assert f[1] == str(3074874 - 5 + 1) and f[3] == "CCATG" + "CAG" * 22 and f[8] == "GT:DP:PM:MC:MCRL:SLR"
+    assert f[9].split(":")[2:5] == ["dist", "8,9", "7x1|8x10|9x1,8x2|9x12"]

@@ -16,12 +16,19 @@ def test_error_free_reads_give_their_allele(gpu_ctx, tmp_path):
     t = make_dataset(str(tmp_path), n_loci=25, reads_per_locus=10, read_len=2500, seed=11)
     rep = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"])
     assert len(rep["results"]) == 25
+    bam, (block,) = read_bam(t["paths"]["bam"]), load_loci(t["paths"]["loci"])
+    segs_of = {l.t_idx: bam.fetch(l.contig, l.left_flank_coord, l.right_flank_coord) for l in block}
     for res, truth in zip(rep["results"], t["loci"]):
         assert res["call"] is None and res["read_peaks_called"] is False and res["ref_cn"] == truth["ref_cn"] and res["motif"] == truth["motif"]
         assert set(res["reads"]) == set(truth["reads"])
         for name, rd in res["reads"].items():
             assert rd["cn"] == truth["reads"][name] and rd["sc"] == 2.0 and rd["s"] in "+-"
-            assert abs(rd["w"] - 0.1) < 1e-12 and rd["sl"] == truth["reads"][name] * len(truth["motif"])
+            assert rd["sl"] == truth["reads"][name] * len(truth["motif"])
+        # read weights (call_locus.py:1254-1259): (L + t - 2) / (L - t + 1), L = mean length of the locus' reads, t = flanks + tract
+        lens = np.array([s.length for s in segs_of[res["locus_index"]]], np.float64)
+        for name, rd in res["reads"].items():
+            t_ = rd["sl"] + 140
+            assert abs(rd["w"] - (lens.mean() + t_ - 2) / (lens.mean() - t_ + 1)) < 1e-12
 
 
 def test_noisy_reads_match_the_oracle_on_the_extracted_triples(gpu_ctx, tmp_path):
@@ -204,3 +211,21 @@ def test_indexed_and_whole_file_access_give_the_same_report(gpu_ctx, tmp_path):
             n += 1
             hit += rd["cn"] == truth[(int(l_), int(r_))]
     assert n == 450 * 9 and hit > 0.95 * n
+
+
+def test_report_rows_and_vcf_match_the_golden_fixture(gpu_ctx, tmp_path):
+    """tests/golden/report_rows.json / report.vcf (tests/golden/make_report_golden.py): the rows `python -m strkit_amd call`
+    writes - read records with the keys of call_locus.py:1279-1288, locus fields of :1040-1047,1340-1352 - and their VCF."""
+    import os
+    from strkit_amd.frontend.output import allele_calling_inputs, write_vcf
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    gold = json.load(open(os.path.join(g, "report_rows.json")))
+    t = make_dataset(str(tmp_path), **gold["params"])
+    rep = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"], realign=True, sample_id="golden")
+    assert json.loads(json.dumps(rep["results"])) == gold["results"]
+    write_vcf(rep, str(tmp_path / "o.vcf"), Fasta(t["paths"]["ref"]), date="20261004")
+    assert open(tmp_path / "o.vcf").read() == open(os.path.join(g, "report.vcf")).read()
+    row = rep["results"][0]
+    assert set(next(iter(row["reads"].values()))) <= {"s", "cn", "w", "sc", "sl", "realn"}
+    cns, w = allele_calling_inputs(row)             # what allele.call_alleles receives (call_locus.py:188-204)
+    assert cns.dtype == np.int32 and len(cns) == len(row["reads"]) and abs(w.sum() - 1.0) < 1e-12
