@@ -67,9 +67,10 @@ def make_batches(cfg: int, n_loci: int, n_batches: int, rank: int, pool) -> list
 
 def _cpu_worker(args):
     """One CPU process of the baseline: the oracle's per-locus loop over a slice of loci."""
-    cfg, lo, hi, seed_shift = args
+    cfg, lo, hi, seed_shift, simd = args
     import oracle  # CPU baseline leg only (test infrastructure, never on the product path)
     from strkit_amd.synth import make_config
+    oracle.set_simd(bool(simd))
     b = make_config(cfg, n_loci=hi, seed_shift=seed_shift).locus_slice(lo, hi)
     t0 = time.perf_counter()
     cells = 0
@@ -84,20 +85,31 @@ def _cpu_worker(args):
 
 def cpu_baseline(cfg: int, sample_loci: int, pool, cores: int) -> dict:
     """Oracle (CPU restatement of the reference algorithm) on a bounded sample, all host cores, loci sharded over
-    processes as strkit/call/call_sample.py:414 does.  Runs BEFORE HIP is initialised so the forked workers never
-    see a GPU context."""
-    per = max(1, sample_loci // cores)
-    jobs = [(cfg, i * per, (i + 1) * per, 0) for i in range(cores)]
-    t0 = time.perf_counter()
-    res = pool.map(_cpu_worker, jobs)
-    wall = time.perf_counter() - t0
-    reads = sum(r[0] for r in res)
-    busy = max(r[1] for r in res)
-    return {"value": reads / busy, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {per * cores} loci ({reads} reads) of one 1 000-locus instance of the workload, scalar C oracle "
-                      f"with the reference's per-locus memoisation, {cores} processes, {busy:.1f} s busy each "
-                      f"({busy * cores:.0f} core-seconds; {wall:.1f} s wall incl. input generation)",
-            "reads_per_s_per_core": reads / busy / cores, "gcups": sum(r[2] for r in res) / busy / 1e9}
+    processes as strkit/call/call_sample.py:414 does — once with the scalar code and once with the inter-sequence AVX2
+    variant (oracle/strk_simd.c: sixteen candidate sizes of a read per pass, the class of code parasail is), whose rate is
+    the reported baseline.  Runs BEFORE HIP is initialised so the forked workers never see a GPU context."""
+    import oracle
+    out = {}
+    for name, simd, loci in (("scalar", 0, sample_loci), ("simd", 1, 4 * sample_loci)):
+        if simd and not oracle.set_simd(True):
+            continue
+        per = max(1, min(UNIT_LOCI, loci // cores))
+        # every process takes its own slice; beyond one instance of the config the processes use further instances
+        jobs = [(cfg, (i * per) % UNIT_LOCI, (i * per) % UNIT_LOCI + per, (i * per) // UNIT_LOCI, simd) for i in range(max(cores, loci // per))]
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_worker, jobs)
+        wall = time.perf_counter() - t0
+        reads = sum(r[0] for r in res)
+        busy = sum(r[1] for r in res) / cores            # jobs are dealt to `cores` processes
+        out[name] = {"value": reads / busy, "unit": "reads/s", "cores": cores, "reads": reads, "busy_s_per_core": busy, "wall_s": wall,
+                     "reads_per_s_per_core": reads / busy / cores, "gcups": sum(r[2] for r in res) / busy / 1e9}
+    oracle.set_simd(False)
+    best = out.get("simd", out["scalar"])
+    return {"value": best["value"], "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"{best['reads']} reads ({best['reads'] // 30} loci) of the same workload, C restatement of the reference algorithm with its "
+                      f"per-locus memoisation, {'AVX2 inter-sequence int16 scoring (16 candidate sizes per pass)' if 'simd' in out else 'scalar scoring'}, "
+                      f"{cores} processes, {best['busy_s_per_core']:.1f} s busy each ({best['busy_s_per_core'] * cores:.0f} core-seconds)",
+            "reads_per_s_per_core": best["reads_per_s_per_core"], "gcups": best["gcups"], "scalar": out["scalar"], "simd": out.get("simd")}
 
 
 def pmc_summary(kernel: str) -> dict | None:

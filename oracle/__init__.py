@@ -29,7 +29,8 @@ _i64p = C.POINTER(C.c_int64)
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "strk_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "strk_simd.c")))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libstrk_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -60,6 +61,9 @@ def lib():
                                      C.POINTER(C.c_uint32), C.c_int32]
         L.strk_o_realign.restype = C.c_int32
         L.strk_o_ref_repeat_count.argtypes = ([C.c_int32] + [_u8p, C.c_int32] * 4 + [C.c_int32] * 8 + [_i32p])
+        L.strk_o_set_simd.restype = C.c_int
+        L.strk_o_set_simd.argtypes = [C.c_int]
+        L.strk_o_simd_available.restype = C.c_int
         L.strk_o_init()
         _lib = L
     return _lib
@@ -170,3 +174,9 @@ def realign(s1, s2, open_: int = 7, ext: int = 0, gap_pref: int = 0):
     if n < 0:
         raise ValueError("realign: empty input" if n == -2 else "realign: CIGAR capacity")
     return sc.value, e2.value, np.frombuffer(cig, dtype=np.uint32, count=n).copy()
+
+
+def set_simd(on: bool) -> bool:
+    """Candidate scores from the AVX2 inter-sequence pass (strk_simd.c) where it applies: same results, lower cost — the
+    "simd" CPU baseline of bench.py.  Returns whether it is in effect (False on a CPU without AVX2)."""
+    return bool(lib().strk_o_set_simd(int(on)))

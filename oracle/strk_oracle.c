@@ -201,9 +201,38 @@ typedef struct {
     int32_t ndb;
     int32_t flags;
     int64_t cells; /* DP cells evaluated, for GCUPS reporting */
+    /* inter-sequence SIMD (strk_simd.c): the scores of sixteen consecutive sizes from one pass, kept per read */
+    int32_t simd_lo, simd_ok;
+    int32_t simd_scores[16];
 } cand_ctx;
 
+/* strk_simd.c */
+int strk_o_simd_available(void);
+int64_t strk_o_simd_scores16(const uint8_t* db, int32_t ndb, const uint8_t* fl, int32_t nfl, const uint8_t* fr, int32_t nfr,
+                             const uint8_t* motif, int32_t m, int32_t lo, int32_t* scores);
+static int g_simd = 0;
+/* 1: candidate scores come from the AVX2 inter-sequence pass where it applies (all end gaps free, scores within int16,
+ * a CPU with AVX2); results are identical, only the cost differs.  Returns what is in effect. */
+int strk_o_set_simd(int on) {
+    g_simd = on && strk_o_simd_available();
+    return g_simd;
+}
+
 static int32_t score_candidate(cand_ctx* c, int32_t i) {
+    if (g_simd && c->flags == STRK_O_SG_ALL && i >= 0) {
+        if (!c->simd_ok || i < c->simd_lo || i >= c->simd_lo + 16) {
+            const int32_t lo = i - 4 > 0 ? i - 4 : 0;   /* the search asks for start-3 first and then climbs either way */
+            const int64_t cells = strk_o_simd_scores16(c->db, c->ndb, c->fl, c->nfl, c->fr, c->nfr, c->motif, c->m, lo, c->simd_scores);
+            if (cells >= 0) {
+                c->simd_lo = lo;
+                c->simd_ok = 1;
+                c->cells += cells;
+            } else {
+                c->simd_ok = 0;
+            }
+        }
+        if (c->simd_ok && i >= c->simd_lo && i < c->simd_lo + 16) return c->simd_scores[i - c->simd_lo];
+    }
     int32_t nq = c->nfl + i * c->m + c->nfr;
     uint8_t* q = (uint8_t*)malloc((size_t)(nq > 0 ? nq : 1));
     memcpy(q, c->fl, (size_t)c->nfl);
@@ -219,7 +248,7 @@ static int32_t score_candidate(cand_ctx* c, int32_t i) {
 int32_t strk_o_candidate_score(const uint8_t* tr, int32_t ntr, const uint8_t* fl, int32_t nfl,
                                const uint8_t* fr, int32_t nfr, const uint8_t* motif, int32_t m,
                                int32_t i, int32_t flags) {
-    cand_ctx c = {tr, fl, fr, motif, ntr, nfl, nfr, m, NULL, nfl + ntr + nfr, flags, 0};
+    cand_ctx c = {tr, fl, fr, motif, ntr, nfl, nfr, m, NULL, nfl + ntr + nfr, flags, 0, 0, 0, {0}};
     c.db = (uint8_t*)malloc((size_t)(c.ndb > 0 ? c.ndb : 1));
     memcpy(c.db, fl, (size_t)nfl);
     memcpy(c.db + nfl, tr, (size_t)ntr);
@@ -263,7 +292,7 @@ int strk_o_repeat_count(int32_t start_count, const uint8_t* tr, int32_t ntr, con
                         int32_t m, int32_t max_iters, int32_t lsr, int32_t step, int32_t tie_rule,
                         int32_t flags, int32_t* out_cn, int32_t* out_score, int32_t* out_n,
                         int64_t* out_cells) {
-    cand_ctx c = {tr, fl, fr, motif, ntr, nfl, nfr, m, NULL, nfl + ntr + nfr, flags, 0};
+    cand_ctx c = {tr, fl, fr, motif, ntr, nfl, nfr, m, NULL, nfl + ntr + nfr, flags, 0, 0, 0, {0}};
     c.db = (uint8_t*)malloc((size_t)(c.ndb > 0 ? c.ndb : 1));
     memcpy(c.db, fl, (size_t)nfl);
     memcpy(c.db + nfl, tr, (size_t)ntr);

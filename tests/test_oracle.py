@@ -249,3 +249,38 @@ def test_golden_realign_cases():
     for c in cases:
         sc, e2, cg = oracle.realign(c["ref"], c["read"], c["open"], c["extend"], c["gap_pref"])
         assert (sc, e2, "".join(f"{n}{o}" for n, o in cigar_tuples(cg))) == (c["score"], c["end_ref"], c["cigar"])
+
+
+def test_simd_scoring_equals_the_scalar_restatement():
+    """oracle/strk_simd.c (AVX2, sixteen candidate sizes of a read per pass: bench.py's "simd" CPU baseline) against the
+    scalar code: per-candidate scores and whole searches, wildcard and IUPAC alphabets, empty tracts, bad estimates."""
+    import ctypes as C
+    if not oracle.set_simd(True):
+        pytest.skip("this CPU has no AVX2")
+    try:
+        rng = np.random.default_rng(9)
+        L = oracle.lib()
+        L.strk_o_simd_scores16.restype = C.c_int64
+        for alpha in (ALPHA_ACGT + "XN", ALPHA_IUPAC):
+            for _ in range(40):
+                motif, reads = random_locus(rng, 1, motif_len=(1, 7), cn=(0, 20), flank=(1, 40), alpha=alpha, edits=(0, 5))
+                fl, tr, fr = reads[0]
+                db = (fl + tr + fr).encode()
+                lo = int(rng.integers(0, 12))
+                out = (C.c_int32 * 16)()
+                cells = L.strk_o_simd_scores16(db, len(db), fl.encode(), len(fl), fr.encode(), len(fr), motif.encode(), len(motif), lo, out)
+                assert cells > 0
+                oracle.set_simd(False)
+                want = [oracle.candidate_score(tr, fl, fr, motif, lo + k) for k in range(16)]
+                oracle.set_simd(True)
+                assert list(out) == want, (motif, fl, tr, fr, lo)
+        for _ in range(60):
+            motif, reads = random_locus(rng, 4, motif_len=(1, 6), cn=(0, 30), flank=(1, 70), alpha=ALPHA_ACGT + "X")
+            for fl, tr, fr in reads:
+                start = max(0, round(len(tr) / len(motif)) + int(rng.integers(-7, 8)))
+                oracle.set_simd(False)
+                a = oracle.repeat_count(start, tr, fl, fr, motif)
+                oracle.set_simd(True)
+                assert oracle.repeat_count(start, tr, fl, fr, motif) == a
+    finally:
+        oracle.set_simd(False)
