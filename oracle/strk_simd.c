@@ -85,7 +85,9 @@ int64_t strk_o_simd_scores16(const uint8_t* db, int32_t ndb, const uint8_t* fl, 
         lastcol = _mm256_max_epi16(lastcol, _mm256_or_si256(_mm256_and_si256(on, left), _mm256_andnot_si256(on, lastcol)));
     }
     __m256i best = lastcol;
-    for (int32_t j = 0; j <= ndb; j++) best = _mm256_max_epi16(best, H[j]);  /* free end along the window: the last rows */
+    /* free end along the window: the lanes' last rows (column 0 of the last row and row 0 of the last column are boundary
+     * nodes, not alignment ends: the scalar restatement and parasail leave them out too) */
+    for (int32_t j = 1; j <= ndb; j++) best = _mm256_max_epi16(best, H[j]);
     int16_t out[16];
     _mm256_storeu_si256((__m256i*)out, best);
     for (int k = 0; k < 16; k++) scores[k] = lo + k < 0 ? INT32_MIN : (nq[k] == 0 ? 0 : out[k]);
