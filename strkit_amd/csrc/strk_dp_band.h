@@ -41,17 +41,35 @@ __host__ __device__ constexpr int max_band_wave_lds(int c) {
 constexpr int kBandWaveLds = max_band_wave_lds(kNumBandClasses - 1);
 constexpr int kBandNeg16 = -20000;
 // Fixed symbol classes of the band kernels: what an alignment file's reads hold after wildcarding (call_locus.py:79):
-// A C G T, N, the wildcard X and '*' (any byte outside the alphabet).  v_perm selector = class index; a read with another
-// symbol (an IUPAC code) takes the exact kernels, whose classes are per read.  Row-word table: entries 0..17 by encoded
-// symbol (16 = '*', 17 = no row), then one entry per class for flank rows, which are staged as selector bytes.
-constexpr int kBandNClass = 7;
+// A C G T, N and the wildcard X, in either case.  v_perm selector = class index = bits 3:1 of the ASCII code (A 0, C 1, T 2,
+// G 3, X 4, N 7: four window bytes become four selectors with one shift and one AND, a v_perm of the expected letters and
+// an XOR tell whether all four really are one of the six); a read with another symbol (an IUPAC code, a byte outside the
+// alphabet) takes the exact kernels, whose classes are per read.
+// Row-word tables (8 bytes per row symbol, one table per pass): bytes 0..4 and 7 = W + 2g against the six classes, byte 5 =
+// what a pad column in FRONT of the window adds on the diagonal, byte 6 = the same for a pad column BEHIND it.  A free left
+// boundary is G(r, j <= 0) = g r in G-space, i.e. "+ g per row" along every diagonal left of column 1: the pass whose left
+// side those pads are gets g there when that end is free (forward: front pads / candidate begin; backward, in reversed
+// coordinates: back pads / candidate end) and 0 otherwise — the pads then carry the boundary value by themselves.  The same
+// for the top boundary G(0, j) = g j: the rows in front of the matrix ("no row" symbol) add g per real column when the
+// window's end on that side is free.  Only the cell right next to the boundary column / row still needs the boundary value
+// handed in (one step per pass, band_pass).
+// Entries: 0..17 by encoded symbol (16 = '*', 17 = no row), then one entry per class for flank rows, which are staged as
+// selector bytes.  Row symbols are staged PRE-MULTIPLIED by 8 (the table offset of their word).
 constexpr int kBandTblClass0 = 18;
-__host__ __device__ constexpr int band_class_symbol(int c) { return c < 4 ? c : (c == 4 ? 15 /* X */ : (c == 5 ? 14 /* N */ : kStar)); }
+constexpr int kBandSelFront = 5, kBandSelBack = 6;
+constexpr int kBandTblBytes = 256;   // per pass: 26 entries used; a stale row symbol (any byte) stays inside it
+// encoded symbol (strk_scoring.h alphabet "ACGTRYSWKMBDHVNX") of selector c, -1 for the two pad selectors
+__host__ __device__ constexpr int band_class_symbol(int c) {
+    return c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 3 : (c == 3 ? 2 : (c == 4 ? 15 : (c == 7 ? 14 : -1)))));
+}
+constexpr unsigned kBandLetterLo = 0x47544341u, kBandLetterHi = 0x4E000058u;   // "ACTG", "X\0\0N"
+typedef const __attribute__((address_space(3))) uint8_t* lds_cu8;
 
 struct BandCtx {
     int lig;
     bool first, last;
-    const uint2* tbl;
+    int notFirst, notLast;   // 0 in the first / last lane of a group, else all ones
+    const uint8_t* tbl;      // the pass's row-word table (set by band_wave before each pass)
     const uint8_t* selb;   // class-byte array: selb[pad + x] <-> db[x], 0x0c elsewhere
     int pad, maxidx, ndb;
     const uint8_t* flL;    // on-the-fly forward rows: 256 left-flank symbols, 256 motif symbols
@@ -59,9 +77,34 @@ struct BandCtx {
     int nfl, m;
 };
 
+// min over the (at most eight) groups of a wave of a value that is uniform inside each group
+__device__ __forceinline__ int wave_min_over_groups(int v) {
+    int m = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+    for (int l = 8; l < 64; l += 8) m = min(m, __builtin_amdgcn_readlane(v, l));
+    return m;
+}
+// lane l gets v of lane l - 1 (l + 1), the first (last) lane of every group 0 — the value of a cell outside the band in
+// G-space.  One instruction: the DPP shift zero-fills at the ends of its row / of the wave and is an operand of the AND
+// that clears the seam lanes where a group is shorter than that.
+template <int G>
+__device__ __forceinline__ int from_left0(int v, int notFirst) {
+    const int x = __builtin_amdgcn_update_dpp(0, v, G <= 16 ? kDppRowShr1 : kDppWaveShr1, 0xf, 0xf, true);
+    return (G == 16 || G == 64) ? x : (x & notFirst);
+}
+template <int G>
+__device__ __forceinline__ int from_right0(int v, int notLast) {
+    const int x = __builtin_amdgcn_update_dpp(0, v, G <= 16 ? kDppRowShl1 : kDppWaveShl1, 0xf, 0xf, true);
+    return (G == 16 || G == 64) ? x : (x & notLast);
+}
+
 // One banded pass over `nrows` rows.  BWD = false: forward pass (columns = db, left to right);
 // BWD = true: backward pass in reversed coordinates (columns = reversed db).  dlo_ is the first
 // diagonal of the band, topFree/leftFree the free-end flags of the top row / left column.
+// Steps come in two forms.  The plain one takes 0 (outside the band) from both sides.  The other one also hands in the
+// boundary values: the row-0 pattern above the last lane's first row (step G - 1) and the left-boundary column while it lies
+// right next to the band (step -dlo of each group; the pads further left carry the boundary by themselves, see the row-word
+// tables above).  Only the pairs of steps that hold one of those moments run the second form.
 template <int G, bool BWD, bool FLY, bool LMAX>
 __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsym, int nrows, int dlo_, bool topFree,
                                           bool leftFree, int nEff, int fork0, int m, int cmin, int ncol, int* comb,
@@ -77,110 +120,150 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     unsigned sel[4];
 #pragma unroll
     for (int k = 0; k < 16; ++k) Ha[k] = g0(-x.lig + d0 + k);
+    const int jb0 = 1 - x.lig + d0;                   // column of slot 0 at the row of step 0 (step t: jb0 + t)
     {
-        const int j0 = 1 - x.lig + d0;                // column of slot 0 at the row of step 0
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             unsigned v = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) v |= (unsigned)x.selb[col_addr(j0 + 4 * q + b)] << (8 * b);
+            for (int b = 0; b < 4; ++b) v |= (unsigned)x.selb[col_addr(jb0 + 4 * q + b)] << (8 * b);
             sel[q] = v;
         }
     }
     const int T = (wave_max_over_groups(nrows > 0 ? nrows + G - 1 : 0) + 1) & ~1;
     const int dhi_ = dlo_ + 16 * G - 1;
     int houtL = Ha[15];
-    int gr = -g * x.lig;                               // g * (row finished before step 0)
-    int jb = 1 - x.lig + d0;                           // column of slot 0 at the current step's row
-    int forkG = (!BWD && nEff > 0) ? g * fork0 : 0x7fffffff;
-    if (BWD) forkG = g * nrows;                        // the backward pass has one event: its last row
+    // the step at which this lane finishes its next fork row (forward), its last row (backward: the one event of that pass)
+    int forkT = (!BWD && nEff > 0) ? fork0 - 1 + x.lig : 0x7fffffff;
+    if (BWD && nrows > 0) forkT = nrows - 1 + x.lig;
     int forkIdx = 0;
-    const int gm = g * m;
     // classes of band_class_lmax: running maximum of the last column over the in-band rows.  Right of column |db|
     // the pads replicate G(r, |db|), so from row |db| - dhi on the last lane's slot 15 holds that value.
     int lastmax = kNegInf;
+    int gr = -g * x.lig;                               // g * (row finished before step 0): LMAX only
     const int grFirst = g * max(1, ncols - dhi_);
-    // row symbols: staged in LDS with G-1 null rows in front (pa[t] is this lane's row at step t), or
-    // generated two steps ahead from the left flank and the motif phase (long windows)
-    const uint8_t* pa = rowsym + (G - 1) - x.lig;
+    // row symbols (8 * table index): staged in LDS with G-1 null rows in front (this lane's row at step t is psym[t]), or
+    // generated two steps ahead from the left flank and the motif phase (long windows).  psym / pnb are running LDS
+    // addresses, advanced once per pair of steps; the steps read at constant offsets from them.
+    lds_cu8 psym = (lds_cu8)(rowsym + (G - 1) - x.lig);
+    lds_cu8 const tbl = (lds_cu8)x.tbl;
+    auto row_word = [&](unsigned sym8) -> uint2 {
+        const unsigned long long v = *reinterpret_cast<const __attribute__((address_space(3))) unsigned long long*>(tbl + sym8);
+        return make_uint2((unsigned)v, (unsigned)(v >> 32));
+    };
     int rowi = -x.lig, ph = 0;
     auto next_sym = [&]() -> unsigned {
-        unsigned sym = kNullSym;
+        unsigned sym = 8 * kNullSym;
         if (rowi >= 0) sym = rowi < x.nfl ? x.flL[rowi] : x.motifL[ph];
         if (rowi >= x.nfl) { ++ph; if (ph == x.m) ph = 0; }
         ++rowi;
         return sym;
     };
-    uint2 wordNext;
-    unsigned symNext;
-    if (FLY) { wordNext = x.tbl[next_sym()]; symNext = next_sym(); }
-    else { wordNext = x.tbl[pa[0]]; symNext = pa[1]; }
-    unsigned nbNext = x.selb[col_addr(jb + 16)];       // class byte entering at the next row
-#define STRK_BAND_STEP(SRC, DST, TT, EDGE)                                                         \
+    // row words are fetched two steps ahead (wordE / wordO: even / odd steps).  Every LDS byte is loaded at the head of a
+    // step and used at its end, in the same basic block: the compiler then knows that ds_read_u8 zero-extends (a value that
+    // crosses the fork-row branch would be masked again).
+    uint2 wordE, wordO;
+    if (FLY) { wordE = row_word(next_sym()); wordO = row_word(next_sym()); }
+    else { wordE = row_word(psym[0]); wordO = row_word(psym[1]); }
+    // class byte entering the lane's window after step t: column jb0 + t + 16
+    lds_cu8 pnb = (lds_cu8)(x.selb + col_addr(jb0 + 16)) - (BWD ? 1 : 0);
+#define STRK_BAND_STEP(SRC, DST, TT, ODD, EDGE)                                                    \
     {                                                                                              \
-        const uint2 word = wordNext;                                                               \
-        wordNext = x.tbl[symNext];                                                                 \
-        symNext = FLY ? next_sym() : (unsigned)pa[(TT) + 2];                                       \
-        const unsigned nb = nbNext;                                                                \
-        nbNext = x.selb[col_addr(jb + 17)];                                                        \
-        /* lane 0 works on row TT+1; left of the band lies the left boundary while j-1 <= 0 */      \
-        const int keepL = ((EDGE) && (TT) + dlo_ <= 0 && leftFree) ? g * ((TT) + 1) : 0;            \
-        const int leftEdge = from_left<G>(keepL, houtL, x.first);                                  \
-        /* the last lane works on row TT-G+2; above row 1 lies the row-0 pattern, else -inf */      \
-        const int rl = (TT) - G + 2;                                                               \
-        const int keepU = ((EDGE) && rl <= 1) ? g0(rl + dhi_) : 0;                                 \
+        STRK_BAND_FORK(SRC, (TT) - 1)                                                              \
+        const uint2 word = (ODD) ? wordO : wordE;                                                  \
+        unsigned sym2 = FLY ? next_sym() : (unsigned)psym[2 + (ODD)];   /* row of step TT + 2 */   \
+        unsigned nb = pnb[BWD ? 1 - (ODD) : (ODD)];                                                \
+        int leftEdge, keepU = 0;                                                                   \
+        if (EDGE) {                                                                                \
+            /* lane 0 works on row TT+1; left of the band lies the left boundary while j-1 <= 0 */  \
+            const int keepL = ((TT) + dlo_ <= 0 && leftFree) ? g * ((TT) + 1) : 0;                  \
+            leftEdge = from_left<G>(keepL, houtL, x.first);                                        \
+            /* the last lane works on row TT-G+2; above row 1 lies the row-0 pattern, else -inf */  \
+            const int rl = (TT) - G + 2;                                                           \
+            keepU = rl <= 1 ? g0(rl + dhi_) : 0;                                                   \
+        } else {                                                                                   \
+            leftEdge = from_left0<G>(houtL, x.notFirst);                                           \
+        }                                                                                          \
         const unsigned w0 = __builtin_amdgcn_perm(word.y, word.x, sel[0]);                         \
         const unsigned w1 = __builtin_amdgcn_perm(word.y, word.x, sel[1]);                         \
         const unsigned w2 = __builtin_amdgcn_perm(word.y, word.x, sel[2]);                         \
         const unsigned w3 = __builtin_amdgcn_perm(word.y, word.x, sel[3]);                         \
         DST[0] = max(max(SRC[1], leftEdge), SRC[0] + (int)(w0 & 0xffu));                           \
-        const int upEdge = from_right<G>(keepU, DST[0], x.last);                                   \
+        const int upEdge = (EDGE) ? from_right<G>(keepU, DST[0], x.last) : from_right0<G>(DST[0], x.notLast); \
         _Pragma("unroll") for (int k = 1; k < 15; ++k) {                                           \
             const unsigned wq = k < 4 ? w0 : (k < 8 ? w1 : (k < 12 ? w2 : w3));                     \
             DST[k] = max(max(SRC[k + 1], DST[k - 1]), SRC[k] + (int)((wq >> (8 * (k % 4))) & 0xffu)); \
         }                                                                                          \
         DST[15] = max(max(upEdge, DST[14]), SRC[15] + (int)(w3 >> 24));                            \
         houtL = DST[15];                                                                           \
-        if (LMAX && !BWD) lastmax = (gr + g >= grFirst) ? max(lastmax, houtL - (gr + g)) : lastmax; \
+        /* the two bytes as plain 32-bit values from here on (zero-extended by the load, which the compiler knows in   \
+           this block only: their uses may be moved below the next fork-row branch) */                  \
+        asm volatile("" : "+v"(nb), "+v"(sym2));                                                   \
+        if (LMAX && !BWD) {                                                                        \
+            gr += g;                                                                               \
+            lastmax = (gr >= grFirst) ? max(lastmax, houtL - gr) : lastmax;                        \
+        }                                                                                          \
         sel[0] = __builtin_amdgcn_alignbyte(sel[1], sel[0], 1);                                    \
         sel[1] = __builtin_amdgcn_alignbyte(sel[2], sel[1], 1);                                    \
         sel[2] = __builtin_amdgcn_alignbyte(sel[3], sel[2], 1);                                    \
         sel[3] = __builtin_amdgcn_alignbyte(nb, sel[3], 1);                                        \
-        gr += g;                                                                                   \
-        if (gr == forkG) {                                                                         \
-            if (BWD) {                                                                             \
-                /* last row: slot k is reversed column jb + k, i.e. db node ndb - (jb + k) */       \
-                _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                   \
-                    const int jp = jb + k, idx = ncols - jp - cmin;                                \
-                    if (jp >= 0 && jp <= ncols && idx >= 0 && idx < ncol) b0col[idx] = (short)DST[k]; \
-                }                                                                                  \
-                forkG = 0x7fffffff;                                                                \
-            } else {                                                                               \
-                const short* bc = b0col + (jb - cmin);                                             \
-                int acc = kNegInf;                                                                 \
-                _Pragma("unroll") for (int k = 0; k < 16; k += 2)                                  \
-                    acc = max(max(acc, DST[k] + (int)bc[k]), DST[k + 1] + (int)bc[k + 1]);         \
-                atomicMax(&comb[forkIdx], acc);                                                    \
-                if (LMAX && x.last) lmaxA[forkIdx] = lastmax;                                      \
-                ++forkIdx;                                                                         \
-                forkG = forkIdx < nEff ? forkG + gm : 0x7fffffff;                                  \
+        if (ODD) wordO = row_word(sym2); else wordE = row_word(sym2);                              \
+    }
+    // the fork-row work of step TT on that step's output row V.  It runs at the head of the NEXT step, so that a step
+    // itself is one basic block from its LDS byte loads to their uses.
+#define STRK_BAND_FORK(V, TT)                                                                      \
+    if ((TT) == forkT) {                                                                           \
+        const int jb = jb0 + (TT);                      /* column of slot 0 at that step's row */  \
+        if (BWD) {                                                                                 \
+            /* last row: slot k is reversed column jb + k, i.e. db node ndb - (jb + k) */           \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                       \
+                const int jp = jb + k, idx = ncols - jp - cmin;                                    \
+                if (jp >= 0 && jp <= ncols && idx >= 0 && idx < ncol) b0col[idx] = (short)V[k];    \
             }                                                                                      \
+            forkT = 0x7fffffff;                                                                    \
+        } else {                                                                                   \
+            const short* bc = b0col + (jb - cmin);                                                 \
+            int acc = kNegInf;                                                                     \
+            _Pragma("unroll") for (int k = 0; k < 16; k += 2)                                      \
+                acc = max(max(acc, V[k] + (int)bc[k]), V[k + 1] + (int)bc[k + 1]);                 \
+            atomicMax(&comb[forkIdx], acc);                                                        \
+            if (LMAX && x.last) lmaxA[forkIdx] = lastmax;                                          \
+            ++forkIdx;                                                                             \
+            forkT = forkIdx < nEff ? forkT + m : 0x7fffffff;                                       \
         }                                                                                          \
-        ++jb;                                                                                      \
     }
-    // The band touches the left boundary column while t <= -dlo and the row-0 pattern while t <= G - 1: after that
-    // (for every group of the wave) both edge values are the constant 0 and the steps need not compute them.
-    const int tEdge = min(T, (wave_max_over_groups(max(1 - dlo_, G)) + 1) & ~1);
+    // pairs of steps that must hand in a boundary value: the one with step G - 1 (row-0 pattern above the last lane's row 1)
+    // and those with the step -dlo of some group (left-boundary column right next to the band)
+    const bool hasL = nrows > 0 && leftFree && dlo_ <= 0;
+    const int tTop = (G - 1) & ~1;
+    const int tL0 = wave_min_over_groups(hasL ? -dlo_ : 0x3fffffff) & ~1;
+    const int tL1 = wave_max_over_groups(hasL ? -dlo_ : -1);
+    // runs of plain pairs and runs of boundary pairs alternate, each run a loop of its own (one loop with both forms in
+    // its body makes the compiler copy the two row arrays once per pair)
+    auto advance = [&]() {
+        if (!FLY) { psym += 2; asm volatile("" : "+v"(psym)); }
+        pnb += BWD ? -2 : 2;
+        asm volatile("" : "+v"(pnb));
+    };
     int t = 0;
-    for (; t < tEdge; t += 2) {
-        STRK_BAND_STEP(Ha, Hb, t, true)
-        STRK_BAND_STEP(Hb, Ha, t + 1, true)
+    while (t < T) {
+        int ts = T;                                    // the next boundary pair at or after t
+        if (tTop >= t) ts = min(ts, tTop);
+        if (tL1 >= t) ts = min(ts, max(tL0, t));
+        for (; t < ts; t += 2) {
+            STRK_BAND_STEP(Ha, Hb, t, 0, false)
+            STRK_BAND_STEP(Hb, Ha, t + 1, 1, false)
+            advance();
+        }
+        for (; t < T && (t == tTop || (t >= tL0 && t <= tL1)); t += 2) {
+            STRK_BAND_STEP(Ha, Hb, t, 0, true)
+            STRK_BAND_STEP(Hb, Ha, t + 1, 1, true)
+            advance();
+        }
     }
-    for (; t < T; t += 2) {
-        STRK_BAND_STEP(Ha, Hb, t, false)
-        STRK_BAND_STEP(Hb, Ha, t + 1, false)
-    }
+    STRK_BAND_FORK(Ha, T - 1)
 #undef STRK_BAND_STEP
+#undef STRK_BAND_FORK
 }
 
 // Profiling aid (tools/phase_timing.sh builds a private copy of the library with -DSTRK_PHASE_TIMING): shader-clock
@@ -197,9 +280,12 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
 #endif
 
 // Processes 64/G items of band class BC (G = 8 << BC lanes per read), one per group.
-template <int BC>
+// nextA / nextB / nextC: the caller's three steps towards the NEXT chunk (take it from the queue; fetch its records; touch its
+// window bytes), called where each one's result has had time to arrive and where its own loads are not in the way of this
+// chunk's (the memory counter retires loads in order: a load issued behind a slow one waits for it).
+template <int BC, class NA, class NB, class NC>
 __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int4 q1, int4 q2, uint8_t* Lw, const uint8_t* s_enc,
-                                          const uint8_t* s_sel, const uint2* s_tbl) {
+                                          const uint8_t* s_tbl, NA& nextA, NB& nextB, NC& nextC) {
     constexpr int g = kGap, G = 8 << BC;
     constexpr bool FLY = band_class_fly(BC);
     constexpr bool LMAX = band_class_lmax(BC);
@@ -212,7 +298,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     const int grp = lane / G;
     const bool first = lig == 0, last = lig == G - 1;
     uint8_t* const Lg = Lw + grp * lay.group_bytes;
-    const uint2* const tbl = s_tbl;   // row words: the same for every read (fixed symbol classes, band_kernel_body)
+    // row words: the same for every read (fixed symbol classes, band_kernel_body); forward table, then backward table
     int* const comb = reinterpret_cast<int*>(Lg + BandLayout::OFF_COMB);
     int* const misc = reinterpret_cast<int*>(Lg + BandLayout::OFF_MISC);
     int* const lmaxA = reinterpret_cast<int*>(Lg + BandLayout::OFF_LMAX);   // classes of band_class_lmax only
@@ -239,54 +325,54 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     const bool dbBeg = a.end_flags & 1, dbEnd = a.end_flags & 2, cBeg = a.end_flags & 4, cEnd = a.end_flags & 8;
 
     STRK_PHASE(0);
-    // ---- stage: selector bytes with pads (window byte -> fixed symbol class, one LDS look-up per byte), row symbols ----
+    // ---- stage: selector bytes with pads, row symbols ----
     if (first) misc[0] = 0;
     wave_lds_sync();
     {
-        // a dword per lane and eight dwords in flight (the loop is bound by load latency); slots outside the window
-        // get selector 0x0c (constant 0: inert in G-space); a byte outside the fixed classes sets bit 7
+        // pads in front of the window and as far behind it as a pass can reach; the window itself a dword per lane, eight
+        // dwords in flight (the loop is bound by load latency)
+        constexpr unsigned kFront = 0x01010101u * kBandSelFront, kBack = 0x01010101u * kBandSelBack;
+        constexpr int ND = lay.sel_len / 4, PD = lay.pad / 4;
+        constexpr int kBehind = (lay.wd + kBandRowSlack + G + 28 + 3) / 4;
+        static_assert(lay.pad % 4 == 0, "the window starts on a dword of the selector array");
         unsigned other = 0;
         const uint8_t* seq = a.seqs + soff;
-        constexpr int ND = lay.sel_len / 4;
         unsigned* const selw = reinterpret_cast<unsigned*>(selb);
-        for (int d0 = lig; d0 < ND; d0 += 8 * G) {
-            unsigned w[8], ok[8];
+        const int nd = act ? (ndb + 3) >> 2 : 0;
+        for (int d = lig; d < PD; d += G) selw[d] = kFront;
+        for (int d = PD + nd + lig; d < min(ND, PD + nd + kBehind); d += G) selw[d] = kBack;
+        for (int d0 = lig; d0 < nd; d0 += 8 * G) {
+            unsigned w[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int d = d0 + u * G, j0 = 4 * d - lay.pad;
-                unsigned v = 0, o = 0;
-                if (act && d < ND && j0 + 3 >= 0 && j0 < ndb) {
-                    if (j0 >= 0 && j0 + 3 < ndb) {
-                        __builtin_memcpy(&v, seq + j0, 4);   // unaligned dword load
-                        o = 0xfu;
-                    } else {
+                const int d = d0 + u * G;
+                unsigned v = 0;
+                if (4 * d + 3 < ndb) {
+                    __builtin_memcpy(&v, seq + 4 * d, 4);   // unaligned dword load
+                } else {
 #pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                            if (j0 + b >= 0 && j0 + b < ndb) { v |= (unsigned)seq[j0 + b] << (8 * b); o |= 1u << b; }
-                    }
+                    for (int b = 0; b < 3; ++b)
+                        if (4 * d + b < ndb) v |= (unsigned)seq[4 * d + b] << (8 * b);
                 }
                 w[u] = v;
-                ok[u] = o;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int d = d0 + u * G;
-                unsigned out = 0x0c0c0c0cu;
-                if (ok[u] == 0xfu) {
-                    out = (unsigned)s_sel[w[u] & 0xffu] | ((unsigned)s_sel[(w[u] >> 8) & 0xffu] << 8) |
-                          ((unsigned)s_sel[(w[u] >> 16) & 0xffu] << 16) | ((unsigned)s_sel[w[u] >> 24] << 24);
-                } else if (ok[u]) {
-                    out = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        out |= (((ok[u] >> b) & 1u) ? (unsigned)s_sel[(w[u] >> (8 * b)) & 0xffu] : 0x0cu) << (8 * b);
+                unsigned out = (w[u] >> 1) & 0x07070707u;
+                unsigned bad = (w[u] & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(kBandLetterHi, kBandLetterLo, out);
+                if (4 * d + 3 >= ndb) {   // the window's last dword: the bytes behind its end are pads
+                    const unsigned vm = 4 * d >= ndb ? 0u : (0xffffffffu >> (8 * (4 * d + 4 - ndb)));
+                    out = (out & vm) | (kBack & ~vm);
+                    bad &= vm;
                 }
-                other |= out;
-                if (d < ND) selw[d] = out;
+                other |= bad;
+                if (d < nd) selw[PD + d] = out;
             }
         }
         STRK_PHASE(6);
-        if (other & 0x80808080u) misc[0] = 1;
+        nextA();
+        if (other) misc[0] = 1;
         for (int k = lig; k < m; k += G) motifL[k] = act ? s_enc[motif[k]] : (uint8_t)kNullSym;
     }
     wave_lds_sync();
@@ -297,9 +383,12 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
         // row symbols index the row-word table: kBandTblClass0 + class for a flank base (its selector byte), the
         // encoded symbol for a motif base
         if (FLY) {
-            for (int k = lig; k < 256; k += G) cp[k] = (uint8_t)(k < nfl ? kBandTblClass0 + selb[lay.pad + k] : kNullSym);
+            for (int k = lig; k < 256; k += G) cp[k] = (uint8_t)(8 * (k < nfl ? kBandTblClass0 + selb[lay.pad + k] : kNullSym));
+            wave_lds_sync();
+            for (int k = lig; k < m; k += G) motifL[k] = (uint8_t)(8 * motifL[k]);   // (own entries only)
         } else {
-            const int lenP = rowsP + 2 * (G - 1) + 4;
+            // (as far as the longest item of the wave reads: every byte a step can fetch is a valid table offset)
+            const int lenP = wave_max_over_groups(rowsP) + 2 * (G - 1) + 4;
             const int gstep = G % m;
             int ph = (lig - (G - 1) - nfl) % m;
             if (ph < 0) ph += m;
@@ -307,34 +396,39 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
                 const int row = idx - (G - 1);
                 int sym = kNullSym;
                 if (row >= 0 && row < rowsP) sym = row < nfl ? kBandTblClass0 + selb[lay.pad + row] : motifL[ph];
-                cp[idx] = (uint8_t)sym;
+                cp[idx] = (uint8_t)(8 * sym);
                 ph += gstep;
                 if (ph >= m) ph -= m;
             }
         }
-        const int lenT = rowsT + 2 * (G - 1) + 4;
+        const int lenT = wave_max_over_groups(rowsT) + 2 * (G - 1) + 4;
         for (int idx = lig; idx < lenT; idx += G) {
             const int row = idx - (G - 1);
             int sym = kNullSym;
             if (row >= 0 && row < rowsT) sym = kBandTblClass0 + selb[lay.pad + ndb - 1 - row];
-            ct[idx] = (uint8_t)sym;
+            ct[idx] = (uint8_t)(8 * sym);
         }
     }
     wave_lds_sync();
     for (int k = lig; k < lay.maxcol; k += G) b0col[k] = (short)kBandNeg16;
     wave_lds_sync();
+    nextB();
     STRK_PHASE(2);
 
     BandCtx x;
-    x.lig = lig; x.first = first; x.last = last; x.tbl = tbl; x.selb = selb;
+    x.lig = lig; x.first = first; x.last = last; x.notFirst = first ? 0 : -1; x.notLast = last ? 0 : -1; x.selb = selb;
+    asm volatile("" : "+v"(x.notFirst), "+v"(x.notLast));   // plain AND masks: operands of the DPP shifts, not selects
     x.pad = lay.pad; x.maxidx = lay.sel_len - 1; x.ndb = ndb;
     x.flL = cp; x.motifL = motifL; x.nfl = nfl; x.m = m;
     const bool run = act && !fallback && geo.ok;
     const int nEff = run ? n : 0;
     // backward pass (reversed right flank x reversed window), then forward pass with the fork rows
+    x.tbl = s_tbl + kBandTblBytes;
     band_pass<G, true, false, false>(x, ct, (run && !(a.dbg & 2)) ? rowsT : 0, geo.bdlo, dbEnd, cEnd, 0, 0, 1, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
+    nextC();
     STRK_PHASE(3);
+    x.tbl = s_tbl;
     band_pass<G, false, FLY, LMAX>(x, cp, (run && !(a.dbg & 1)) ? rowsP : 0, geo.dlo, dbBeg, cBeg, (a.dbg & 8) ? 0 : nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
     STRK_PHASE(4);
@@ -344,7 +438,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
             int sc = max(comb[k], -(1 << 28)) - g * (R + nfr + ndb);
             if (LMAX && cEnd) sc = max(sc, max(lmaxA[k], -(1 << 28)) - g * ndb);   // ends in the last column, in band
             comb[k] = sc;
-            a.table[a.tab_off[r] + k] = sc;
+            a.table[(long long)r * a.table_stride + k] = sc;   // (a band item is the first of its copies: its own table slot)
         }
     }
     // the bounds of all candidates at once, one per lane (the search below runs on one lane and would otherwise
@@ -358,7 +452,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
         if (run && !(a.dbg & 4)) {
             SeenMask64 seen;
             auto ub = [&](int k) { return ubA[k]; };
-            const CertResult cr = search_replay_cert(a.est_cn[r], a.step, a.lsr, a.max_iters, a.tie_last, comb, lo, n, seen, ub);
+            const CertResult cr = search_replay_cert(q2.w, a.step, a.lsr, a.max_iters, a.tie_last, comb, lo, n, seen, ub);
             if (!cr.uncertain) {
                 certified = true;
                 a.spec[r] = make_int4(cr.res.cn, cr.res.score, cr.res.n_explored,
@@ -394,29 +488,32 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
     const int nA = min(a.counters[kCntClass0 + kBandClass0 + CA], a.list_stride);
     const int nB = min(a.counters[kCntClass0 + kBandClass0 + CB], a.list_stride);
     if (nA + nB <= 0) return;
-    // the row-word table sits in front of the per-wave regions: a stale row symbol (any byte) indexes at most 255 * 8 bytes
-    // past its start, which is still inside this array
-    constexpr int kTblBytes = 256;
+    // the two row-word tables sit in front of the per-wave regions
+    constexpr int kTblBytes = 2 * kBandTblBytes;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kTblBytes + 4 * kBandWaveLds + kLdsSlack];
     __shared__ uint8_t s_enc[256];
-    __shared__ uint8_t s_sel[256];
-    uint2* const s_tbl = reinterpret_cast<uint2*>(lds);
+    uint8_t* const s_tbl = lds;
     {
-        const unsigned sym = c_enc[threadIdx.x];
-        s_enc[threadIdx.x] = (uint8_t)sym;
-        unsigned cls = 0x80u;   // not one of the fixed classes
-        for (int c = 0; c < kBandNClass; ++c) if ((int)sym == band_class_symbol(c)) cls = (unsigned)c;
-        s_sel[threadIdx.x] = (uint8_t)cls;
+        s_enc[threadIdx.x] = c_enc[threadIdx.x];
         if (threadIdx.x < kTblBytes / 8) {
-            const int e = threadIdx.x < kBandTblClass0 ? (int)threadIdx.x : band_class_symbol(min((int)threadIdx.x - kBandTblClass0, kBandNClass - 1));
-            unsigned wlo = 0, whi = 0;
-            if (e < kNSym && (int)threadIdx.x < kBandTblClass0 + kBandNClass) {
-                for (int k = 0; k < kBandNClass; ++k) {
-                    const unsigned b = (unsigned)(c_mat[e][band_class_symbol(k)] + kWBias) & 0xffu;
-                    if (k < 4) wlo |= b << (8 * k); else whi |= b << (8 * (k - 4));
+            const int pass = threadIdx.x / (kBandTblBytes / 8), t = threadIdx.x % (kBandTblBytes / 8);   // 0 forward, 1 backward
+            const bool topFree = a.end_flags & (pass ? 2 : 1), leftFree = a.end_flags & (pass ? 8 : 4);
+            // row symbol of entry t: the encoded symbol itself, or (flank rows, staged as selectors) that of selector t - 18
+            const int e = t < kBandTblClass0 ? t : (t < kBandTblClass0 + 8 ? band_class_symbol(t - kBandTblClass0) : -1);
+            unsigned long long word = 0;
+            for (int k = 0; k < 8; ++k) {
+                const int cs = band_class_symbol(k);
+                unsigned b = 0;
+                if (t == kNullSym) {
+                    // rows in front of the matrix: the row-0 pattern G(0, j) = g j moves one column per row
+                    b = (cs >= 0 && topFree) ? kGap : 0;
+                } else if (e >= 0 && e < kNSym) {
+                    if (cs >= 0) b = (unsigned)(c_mat[e][cs] + kWBias) & 0xffu;
+                    else b = (leftFree && k == (pass ? kBandSelBack : kBandSelFront)) ? kGap : 0;
                 }
+                word |= (unsigned long long)b << (8 * k);
             }
-            s_tbl[threadIdx.x] = make_uint2(wlo, whi);
+            reinterpret_cast<unsigned long long*>(s_tbl)[threadIdx.x] = word;
         }
     }
     __syncthreads();
@@ -459,14 +556,16 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
     (void)fetch(c, act, q0, q1, q2);
     while (c < chA + chB) {
         __builtin_amdgcn_wave_barrier();   // the wave enters every iteration whole (see k_realign_dp)
-        // take the next chunk now and start loading its records: they arrive while this chunk is being processed
-        const int cn = pop();
+        // the next chunk is taken, its records are fetched and its window bytes touched while this one is being processed
+        int cn_raw = 0, cn = 0, g_n = 8;
         bool act_n = false;
         int4 n0 = make_int4(0, 0, 0, 0), n1 = n0, n2 = n0;
-        const int g_n = fetch(cn, act_n, n0, n1, n2);
-        const unsigned sink = touch(act_n, n0, n1, n2, g_n);
-        if (c < chA) band_wave<CA>(a, act, q0, q1, q2, Lw, s_enc, s_sel, s_tbl);
-        else band_wave<CB>(a, act, q0, q1, q2, Lw, s_enc, s_sel, s_tbl);
+        unsigned sink = 0;
+        auto nextA = [&]() { if (lane == 0) cn_raw = atomicAdd(&a.counters[kCntNextBand + SET], 1); };
+        auto nextB = [&]() { cn = __builtin_amdgcn_readfirstlane(cn_raw); g_n = fetch(cn, act_n, n0, n1, n2); };
+        auto nextC = [&]() { sink = touch(act_n, n0, n1, n2, g_n); };
+        if (c < chA) band_wave<CA>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
+        else band_wave<CB>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
         // the touch load's destination register stays reserved until the load has certainly landed
         asm volatile("s_waitcnt vmcnt(0)" : : "v"(sink) : "memory");
         c = cn; act = act_n; q0 = n0; q1 = n1; q2 = n2;

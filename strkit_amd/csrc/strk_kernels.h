@@ -78,7 +78,7 @@ struct KArgs {
     int32_t* table;       // score table
     int32_t* cls_list;    // [kNumLists * list_stride * 2]  (read, chunk start) pairs
     int4* band_recs;      // [kNumBandClasses * list_stride * 3]  everything a band item needs, written by k_plan:
-                          //   (read, locus, nfl, ntr) (nfr, m, lo, n) (seq_off lo, seq_off hi, motif_off, 0)
+                          //   (read, locus, nfl, ntr) (nfr, m, lo, n) (seq_off lo, seq_off hi, motif_off, est_cn)
     int32_t* counters;    // see Counter enum
     unsigned long long* cells;  // DP cells executed; cells[2] / cells[3]: algorithmic bytes (|window| + 16 per read) of the
                                 // items routed to the band kernel / to the exact kernels by k_plan
@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     __shared__ int s_cnt[kNumLists];
     __shared__ int s_base[kNumLists];
     __shared__ unsigned long long s_cells, s_bytes_band, s_bytes_exact;
+    __shared__ unsigned long long s_key[256];
     if (threadIdx.x < kNumLists) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_cells = 0; s_bytes_band = 0; s_bytes_exact = 0; }
     __syncthreads();
@@ -298,10 +299,26 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
         if (s_bytes_exact) atomicAdd(a.cells + 3, s_bytes_exact);
     }
     __syncthreads();
+    // Band items of a block are listed in the order of (band class, motif length, prefix rows): the band kernel runs the
+    // 8 (4, 2, 1) items of a chunk in lock-step for as many steps as the longest one needs, and items with the same motif
+    // length and row count have their fork rows at the same steps.  rank = items of this block that sort before mine.
+    int band_rank = 0;
+    {
+        const unsigned long long mine = band_list >= 0 ? ((unsigned long long)(band_list - kBandClass0) << 60) | ((unsigned long long)m << 40) |
+                                                           ((unsigned long long)(nfl + (lo + n - 1) * m) << 10) | threadIdx.x
+                                                       : ~0ull;
+        s_key[threadIdx.x] = mine;
+        __syncthreads();
+        if (band_list >= 0)
+            for (int q = 0; q < 256; ++q) {
+                const unsigned long long o = s_key[q];
+                band_rank += (o < mine && (o >> 60) == (mine >> 60)) ? 1 : 0;
+            }
+    }
     for (int k0 = 0; k0 < n; k0 += kTableMax) {
         const int nn = min(kTableMax, n - k0);
         const int c = band_list >= 0 ? band_list : classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic, a.ref_mode);
-        const int idx = s_base[c] + atomicAdd(&s_cnt[c], 1);
+        const int idx = s_base[c] + ((band_list >= 0 && !(a.dbg & 16)) ? band_rank : atomicAdd(&s_cnt[c], 1));
         if (idx < a.list_stride) {
             a.cls_list[(size_t)c * a.list_stride * 2 + 2 * idx] = r;
             a.cls_list[(size_t)c * a.list_stride * 2 + 2 * idx + 1] = band_list >= 0 ? l : k0;   // band items: the locus (k0 is 0)
@@ -310,7 +327,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
                 const long long so = a.seq_off[r];
                 rec[0] = make_int4(r, l, nfl, ntr);
                 rec[1] = make_int4(nfr, m, lo, n);
-                rec[2] = make_int4((int)(so & 0xffffffffll), (int)(so >> 32), a.motif_off[l], 0);
+                rec[2] = make_int4((int)(so & 0xffffffffll), (int)(so >> 32), a.motif_off[l], a.est_cn[r]);
             }
         } else {
             atomicOr(&a.counters[kCntError], kErrScratch);

@@ -182,30 +182,31 @@ STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, 
     return b;
 }
 
-STRK_HD int64_t band_diag_len(int64_t nc, int64_t ndb, int64_t d) {
-    int64_t v = d >= 0 ? (nc < ndb - d ? nc : ndb - d) : (nc + d < ndb ? nc + d : ndb);
+// (32-bit arithmetic: band_ub is only asked about items band_geometry accepted, whose lengths are bounded by the class limits)
+STRK_HD int32_t band_diag_len(int32_t nc, int32_t ndb, int32_t d) {
+    const int32_t v = d >= 0 ? (nc < ndb - d ? nc : ndb - d) : (nc + d < ndb ? nc + d : ndb);
     return v < 0 ? 0 : v;
 }
 // longest diagonal among d >= d0 (resp. d <= d0)
-STRK_HD int64_t band_len_beyond_hi(int64_t nc, int64_t ndb, int64_t d0) { return d0 >= 0 ? band_diag_len(nc, ndb, d0) : (nc < ndb ? nc : ndb); }
-STRK_HD int64_t band_len_beyond_lo(int64_t nc, int64_t ndb, int64_t d0) { return d0 <= 0 ? band_diag_len(nc, ndb, d0) : (nc < ndb ? nc : ndb); }
+STRK_HD int32_t band_len_beyond_hi(int32_t nc, int32_t ndb, int32_t d0) { return d0 >= 0 ? band_diag_len(nc, ndb, d0) : (nc < ndb ? nc : ndb); }
+STRK_HD int32_t band_len_beyond_lo(int32_t nc, int32_t ndb, int32_t d0) { return d0 <= 0 ? band_diag_len(nc, ndb, d0) : (nc < ndb ? nc : ndb); }
 
 // Upper bound on the score of every alignment of candidate i the band kernel does not consider.
 STRK_HD int32_t band_ub(const BandGeo& b, int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, int32_t i, int32_t end_flags) {
-    const int64_t ndb = (int64_t)nfl + ntr + nfr, nc = (int64_t)nfl + (int64_t)i * m + nfr, R = (int64_t)nfl + (int64_t)i * m;
-    const int64_t e = ndb - nc;   // diagonal of the end corner
-    int64_t L = band_len_beyond_hi(nc, ndb, (int64_t)b.dlo + b.wd);            // right of the forward band
-    int64_t v = band_len_beyond_lo(nc, ndb, (int64_t)b.dlo - 1);              // left of it
+    const int32_t ndb = nfl + ntr + nfr, R = nfl + i * m, nc = R + nfr;
+    const int32_t e = ndb - nc;   // diagonal of the end corner
+    int32_t L = band_len_beyond_hi(nc, ndb, b.dlo + b.wd);                     // right of the forward band
+    int32_t v = band_len_beyond_lo(nc, ndb, b.dlo - 1);                       // left of it
     if (v > L) L = v;
     v = band_len_beyond_hi(nc, ndb, e - b.bdlo + 1);                          // backward band, original diagonals
     if (v > L) L = v;
-    v = band_len_beyond_lo(nc, ndb, e - ((int64_t)b.bdlo + b.wd - 1) - 1);
+    v = band_len_beyond_lo(nc, ndb, e - (b.bdlo + b.wd - 1) - 1);
     if (v > L) L = v;
     // alignments that end in the last column at a row <= R_i (free candidate end): the classes of band_class_lmax track
     // the in-band ones exactly (the rest leaves the band: first term), the narrowest class bounds them all
     if ((end_flags & 8) && !band_class_lmax(b.cls)) { v = band_len_beyond_hi(nc, ndb, ndb - R); if (v > L) L = v; }
     if (end_flags & 4) { v = band_len_beyond_lo(nc, ndb, -R - 1); if (v > L) L = v; }      // starts on the left edge below R_i
-    return (int32_t)(2 * L);
+    return 2 * L;
 }
 
 // search_replay on a banded table: scores[k] is a lower bound, ub(k) the bound on what the band kernel

@@ -7,9 +7,9 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-
   -o gpurun_out/libstrkit_amd_phase.so strkit_amd/csrc/strk_api.hip -lz -lpthread
 STRKIT_AMD_LIB=$PWD/gpurun_out/libstrkit_amd_phase.so python3 - <<'PY'
 import sys; sys.path.insert(0, ".")
-from strkit_amd.synth import make_config
+from strkit_amd.synth import make_config, LocusBatch
 from strkit_amd.batch import count_loci
-b = make_config(2)
-for _ in range(3):
+b = LocusBatch.concat([make_config(2, seed_shift=k) for k in range(10)])   # one bench step: 10 000 loci
+for _ in range(4):
     count_loci(b)
 PY
