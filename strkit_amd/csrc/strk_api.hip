@@ -232,10 +232,11 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
                      hipStream_t st, bool time_dp) {
     hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, a, mode, d_items, n_items, force_generic);
     static const int tune = getenv("STRKIT_AMD_DP_BLOCKS") ? atoi(getenv("STRKIT_AMD_DP_BLOCKS")) : 0;   // tuning aid
-    // a call that shares the device with other calls in flight takes three quarters of the CU slots per kernel, so
-    // that the tail of one call and the head of the next co-run (this call is counted already); measured on the
-    // bench workload with four calls in flight: 1/2 -> 117 M reads/s, 3/4 and 7/8 -> 125 M, all -> 120 M
-    const int quarters = g_calls_in_flight.load(std::memory_order_relaxed) > 1 ? 3 : 4;
+    // a call that shares the device with other calls in flight takes seven eighths of the CU slots per kernel, so
+    // that the tail of one call and the head of the next co-run (this call is counted already).  tools/grid_sweep.sh on the
+    // bench workload, three calls in flight: 3/4 -> 199 M reads/s, 7/8 -> 206 M, all -> 165 M (the small kernels of the
+    // other calls fit next to resident band blocks: 2 x 208 of a SIMD's 512 VGPRs, no LDS of their own)
+    const int eighths = g_calls_in_flight.load(std::memory_order_relaxed) > 1 ? 7 : 8;
     // expected chunks of the sparsely used kernels, from the previous call of this context (same band mode), scaled
     // to this batch with 50 % head-room; without history every grid is the full resident one.  A grid that turns
     // out too small only makes that kernel slower: every wave pulls chunks until the queue is empty.
@@ -248,7 +249,7 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     };
     if (a.band_mode && mode == 0 && !force_generic) {
         // banded first pass: certified reads are done, the others are appended to the exact lists below
-        const int blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * quarters / 4, (a.list_stride + 3) / 4));
+        const int blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * eighths / 8, (a.list_stride + 3) / 4));
         if (time_dp) (void)hipEventRecord(c->ev[4], st);
         hipLaunchKernelGGL(k_dp_band, dim3(blocks), dim3(256), 0, st, a);
         if (time_dp) (void)hipEventRecord(c->ev[5], st);
@@ -258,7 +259,7 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     if (!force_generic) {
         // persistent-style grid: every wave pulls chunks from the device-side queue until it is empty
         constexpr int kBlocksPerCU = std::max(1, std::min(8, (160 * 1024) / (4 * kWaveLdsBytes + kLdsSlack + 1024)));
-        const int full = std::max(1, std::min(tune > 0 ? tune : 256 * kBlocksPerCU * quarters / 4, (a.list_stride + 3) / 4));
+        const int full = std::max(1, std::min(tune > 0 ? tune : 256 * kBlocksPerCU * eighths / 8, (a.list_stride + 3) / 4));
         const int blocks = a.ref_mode ? full : predicted_blocks(c->hist_exact_chunks, full);
         if (a.ref_mode) hipLaunchKernelGGL(k_dp_ref, dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);

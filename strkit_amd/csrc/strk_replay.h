@@ -23,7 +23,9 @@ struct ReplayArgs {
 
 // One wave per locus: lane i holds the inputs of the locus's i-th read (coalesced loads), the
 // in-order chain over the reads is wave-uniform ALU work on values fetched with v_readlane.
-__global__ void __launch_bounds__(64) k_replay(KArgs a, ReplayArgs p) {
+// (at most 96 VGPRs: a wave of this kernel then fits next to the two resident waves of a band kernel on a SIMD, so that the
+// replay of one call runs inside the band pass of the next one instead of waiting for a free CU slot)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(96))) k_replay(KArgs a, ReplayArgs p) {
     const int l = blockIdx.x;
     const int lane = threadIdx.x;
     const int r_end = a.read_off[l + 1];
