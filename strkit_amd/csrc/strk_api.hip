@@ -366,8 +366,9 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
     }
 #ifdef STRK_PHASE_TIMING
-    fprintf(stderr, "[phase ticks/64] header %d stage %d (of which window bytes %d) tables %d bwd %d fwd %d epilogue %d\n", c->h_counters[40],
-            c->h_counters[41] + c->h_counters[46], c->h_counters[46], c->h_counters[42], c->h_counters[43], c->h_counters[44], c->h_counters[45]);
+    fprintf(stderr, "[phase ticks/64] header %d stage %d (of which pads %d, window bytes %d) tables %d bwd %d fwd %d epilogue %d\n", c->h_counters[40],
+            c->h_counters[41] + c->h_counters[46] + c->h_counters[47], c->h_counters[47], c->h_counters[46], c->h_counters[42], c->h_counters[43],
+            c->h_counters[44], c->h_counters[45]);
 #endif
     int n_band_reads = 0;
     for (int k = 0; k < kNumBandClasses; ++k) n_band_reads += c->h_counters[kCntClass0 + kBandClass0 + k];

@@ -341,6 +341,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
         const int nd = act ? (ndb + 3) >> 2 : 0;
         for (int d = lig; d < PD; d += G) selw[d] = kFront;
         for (int d = PD + nd + lig; d < min(ND, PD + nd + kBehind); d += G) selw[d] = kBack;
+        STRK_PHASE(7);
         for (int d0 = lig; d0 < nd; d0 += 8 * G) {
             unsigned w[8];
 #pragma unroll
