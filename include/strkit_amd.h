@@ -252,6 +252,24 @@ int strk_extract_reads(const uint8_t* buf, int64_t n_bytes, int32_t n_items, con
                        int32_t min_avg_phred, int32_t wildcard_threshold, int32_t* status, int32_t* nfl, int32_t* ntr,
                        int32_t* nfr, uint8_t* seqs, int64_t seq_cap, int64_t* seq_off);
 
+/* ---- alignment file on the device (strk_dbam): BGZF inflation, record scan and read extraction as HIP kernels ----------
+ * Replaces, for a whole file or a stretch of it, the host functions above (what strkit_rust_ext's STRkitBAMReader and
+ * STRkitAlignedSegment do in the reference, call sites strkit/call/call_sample.py:103-121, call_locus.py:837-958): the
+ * decompressed stream lives in HBM only.  One object = one device buffer set; not thread-safe. */
+typedef struct strk_dbam strk_dbam;
+int strk_dbam_open(int device, strk_dbam** out);
+void strk_dbam_close(strk_dbam* d);
+/* Inflates the consecutive BGZF blocks of `comp` (HOST memory) from byte `coff` on, as many as decompress into at most
+ * max_out bytes, into the object's device buffer (one GPU lane per block, CRC checked); *next_coff = offset of the first block
+ * not taken.  Returns the decompressed bytes or a negative STRK_E_* code. */
+int64_t strk_dbam_inflate(strk_dbam* d, const uint8_t* comp, int64_t n_comp, int64_t coff, int64_t max_out, int64_t* next_coff);
+/* bytes [off, off + n) of the decompressed stream -> host (headers, a single record for realignment, tests) */
+int strk_dbam_download(strk_dbam* d, int64_t off, int64_t n, uint8_t* out);
+/* device address and size of the decompressed stream (valid until the next strk_dbam_inflate / strk_dbam_close) */
+void* strk_dbam_data(strk_dbam* d, int64_t* n_bytes);
+/* strk_bgzf_inflate's contract, served by the DEVICE inflater's code compiled for the host, one thread (test aid) */
+int64_t strk_bgzf_inflate_sw(const uint8_t* comp, int64_t n_comp, uint8_t* out, int64_t out_cap);
+
 #ifdef __cplusplus
 }
 #endif

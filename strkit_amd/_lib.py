@@ -47,7 +47,8 @@ class StrkStats(C.Structure):
 EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_repeat_count", "strk_count_loci",
            "strk_count_loci_device", "strk_submit_loci_device", "strk_finish", "strk_score_table",
            "strk_score_ref_table", "strk_ref_repeat_count", "strk_ref_repeat_count_batch", "strk_realign", "strk_bam_scan",
-           "strk_extract_reads", "strk_bgzf_inflate", "strk_bgzf_inflate_range", "strk_bam_names", "strk_bam_scan_piece")
+           "strk_extract_reads", "strk_bgzf_inflate", "strk_bgzf_inflate_range", "strk_bam_names", "strk_bam_scan_piece",
+           "strk_dbam_open", "strk_dbam_close", "strk_dbam_inflate", "strk_dbam_download", "strk_dbam_data", "strk_bgzf_inflate_sw")
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -118,6 +119,18 @@ def load(build: bool = True):
         L.strk_bgzf_inflate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32]
         L.strk_bgzf_inflate_range.restype = C.c_int64
         L.strk_bgzf_inflate_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int32]
+        L.strk_dbam_open.restype = C.c_int
+        L.strk_dbam_open.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.strk_dbam_close.restype = None
+        L.strk_dbam_close.argtypes = [C.c_void_p]
+        L.strk_dbam_inflate.restype = C.c_int64
+        L.strk_dbam_inflate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+        L.strk_dbam_download.restype = C.c_int
+        L.strk_dbam_download.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.strk_dbam_data.restype = C.c_void_p
+        L.strk_dbam_data.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.strk_bgzf_inflate_sw.restype = C.c_int64
+        L.strk_bgzf_inflate_sw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.strk_bam_scan_piece.restype = C.c_int64
         L.strk_bam_scan_piece.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 8 + [C.POINTER(C.c_int64)]
         L.strk_bam_names.restype = C.c_int64

@@ -27,6 +27,7 @@
 #include "strk_kernels.h"
 #include "strk_realign.h"
 #include "strk_frontend.h"
+#include "strk_inflate.h"
 
 extern "C" int strk_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8_t* tr, int32_t tr_len, const uint8_t* fl,
                                  int32_t fl_len, const uint8_t* fr, int32_t fr_len, const uint8_t* motif, int32_t motif_len,
@@ -957,3 +958,5 @@ int64_t strk_bgzf_inflate(const uint8_t* comp, int64_t n_comp, uint8_t* out, int
 }
 
 }  // extern "C"
+
+#include "strk_dbam.inc"

@@ -1,0 +1,289 @@
+// strk_inflate.h — DEFLATE (RFC 1951) decoder for BGZF blocks, written to run one block per GPU lane.
+//
+// The reference reads its alignment files through htslib (pysam / strkit_rust_ext's STRkitBAMReader, call sites
+// strkit/call/call_sample.py:103-121); BGZF — the container of BAM — is a series of independent gzip members of at most
+// 64 KiB each (SAM specification section 4.1), so a file is tens of thousands of independent deflate streams: byte work
+// that is bound by memory, not by arithmetic, and that HBM serves far faster than the host's cores serve zlib.
+//
+// Decoder, per stream (one lane):
+//   * canonical Huffman decoding WITHOUT a per-bit loop and WITHOUT a big look-up table: the next 15 stream bits are
+//     bit-reversed into a left-justified value v; the code length is 1 + the number of per-length limits v has reached
+//     (limit[L] = left-justified end of the codes of length L; fifteen compares against registers, branch-free), the symbol
+//     is sym[base[L] + (v >> (15 - L))].  Per-lane state: 2 x 15 limits in registers, the sorted symbol arrays and the two
+//     base arrays in a 768-byte slot of LDS (strk_inf::Tables).
+//   * a 64-bit bit buffer refilled with one unaligned 8-byte load per token (the caller pads the input by 8 bytes);
+//   * the token loop is a state machine — every iteration a lane either decodes one token or copies up to eight bytes of
+//     a pending match — so that lanes in different states of different streams share one loop body.
+// The same functions compile for the host (tests/test_inflate.py checks them against zlib on every block of a synthetic
+// BAM and on streams of every block type).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define STRK_INF_HD __host__ __device__ inline
+#else
+#define STRK_INF_HD inline
+#endif
+// The loops of a decoder are short, data-dependent and run by one lane each: nothing for a loop vectoriser (and the ROCm 7.2
+// compiler's post-RA scheduler crashes on what -O3 makes of them when it tries).
+#if defined(__clang__)
+#define STRK_INF_LOOP _Pragma("clang loop vectorize(disable) interleave(disable)")
+#else
+#define STRK_INF_LOOP
+#endif
+
+namespace strk_inf {
+
+constexpr int kErrNone = 0, kErrBadBlockType = 1, kErrBadCode = 2, kErrBadLengths = 3, kErrOverrun = 4, kErrBadDistance = 5,
+              kErrStored = 6, kErrSize = 7, kErrCrc = 8;
+
+struct Tables {           // 704 bytes per stream: LDS on the device
+    uint16_t lsym[288];   // literal/length symbols sorted by (code length, symbol)
+    uint16_t dsym[32];    // distance symbols, likewise
+    int16_t lbase[16];    // per length L: index of the first symbol of that length - first code of that length
+    int16_t dbase[16];
+};
+constexpr int kLensBytes = 19 + 286 + 30 + 1;   // code lengths while a block header is being read (global scratch on the device)
+
+struct Limits {
+    uint32_t v[15];       // limit[L - 1], L = 1..15: left-justified (15-bit) end of the codes of length L
+};
+
+STRK_INF_HD uint32_t bitrev15(uint32_t x) {   // the low 15 bits of x, reversed
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(x) >> 17;
+#else
+    x = ((x & 0x5555u) << 1) | ((x >> 1) & 0x5555u);
+    x = ((x & 0x3333u) << 2) | ((x >> 2) & 0x3333u);
+    x = ((x & 0x0f0fu) << 4) | ((x >> 4) & 0x0f0fu);
+    x = ((x & 0x00ffu) << 8) | ((x >> 8) & 0x00ffu);
+    return (x & 0xffffu) >> 1;
+#endif
+}
+
+// Canonical code from `n` code lengths: sorted symbols, bases and limits.  false: over-subscribed or (when more than one
+// code is used) incomplete set of lengths.
+STRK_INF_HD bool build(const uint8_t* lens, int n, uint16_t* sym, int16_t* base, Limits* lim) {
+    int count[16];
+    STRK_INF_LOOP
+    for (int l = 0; l < 16; ++l) count[l] = 0;
+    STRK_INF_LOOP
+    for (int i = 0; i < n; ++i) ++count[lens[i] & 15];
+    int offs[16];
+    int code = 0, used = 0, left = 1;
+    offs[1] = 0;
+    STRK_INF_LOOP
+    for (int l = 1; l <= 15; ++l) {
+        left <<= 1;
+        left -= count[l];
+        if (left < 0) return false;                      // over-subscribed
+        code <<= 1;                                      // first code of length l
+        base[l] = (int16_t)(offs[l] - code);
+        code += count[l];
+        lim->v[l - 1] = (uint32_t)code << (15 - l);
+        used += count[l];
+        if (l < 15) offs[l + 1] = offs[l] + count[l];
+    }
+    base[0] = 0;
+    if (left > 0 && used > 1) return false;              // incomplete (a single code of length 1 is allowed: RFC 1951 3.2.7)
+    STRK_INF_LOOP
+    for (int i = 0; i < n; ++i) {
+        const int l = lens[i] & 15;
+        if (l) sym[offs[l]++] = (uint16_t)i;
+    }
+    return true;
+}
+
+// length of the code that the left-justified 15-bit value v starts with (16: no code)
+STRK_INF_HD int code_len(uint32_t v, const Limits& lim) {
+    int len = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 15; ++k) len += v >= lim.v[k] ? 1 : 0;
+    return len;
+}
+
+struct Stream {
+    const uint8_t* p;     // next input byte to load
+    const uint8_t* end;   // end of the payload (loads may run up to 8 bytes past it: the caller pads)
+    uint64_t buf;
+    int cnt;              // valid bits in buf
+};
+
+STRK_INF_HD void refill(Stream& s) {
+    uint64_t w;
+    memcpy(&w, s.p, 8);
+    s.buf |= w << s.cnt;
+    s.p += (63 - s.cnt) >> 3;
+    s.cnt |= 56;
+}
+STRK_INF_HD uint32_t take(Stream& s, int n) {   // n <= 32 bits, LSB first
+    const uint32_t v = (uint32_t)(s.buf & ((1ull << n) - 1));
+    s.buf >>= n;
+    s.cnt -= n;
+    return v;
+}
+
+// Reads a dynamic block header (HLIT, HDIST, HCLEN, the code-length code, the two sets of lengths) and builds the tables.
+STRK_INF_HD int read_dynamic(Stream& s, Tables* t, uint8_t* lens, Limits* ll, Limits* dl) {
+    refill(s);
+    const int nlen = (int)take(s, 5) + 257, ndist = (int)take(s, 5) + 1, ncode = (int)take(s, 4) + 4;
+    if (nlen > 286 || ndist > 30) return kErrBadLengths;
+    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    STRK_INF_LOOP
+    for (int i = 0; i < 19; ++i) lens[i] = 0;
+    STRK_INF_LOOP
+    for (int i = 0; i < ncode; ++i) {
+        if (s.cnt < 3) refill(s);
+        lens[order[i]] = (uint8_t)take(s, 3);
+    }
+    Limits cl;
+    // the code-length code's symbols and bases live in the distance slots until the real distance code is built
+    if (!build(lens, 19, t->dsym, t->dbase, &cl)) return kErrBadLengths;
+    int i = 0;
+    STRK_INF_LOOP
+    while (i < nlen + ndist) {
+        refill(s);
+        const uint32_t v = bitrev15((uint32_t)s.buf);
+        const int len = code_len(v, cl);
+        if (len > 7) return kErrBadCode;
+        const int sym = t->dsym[t->dbase[len] + (int)(v >> (15 - len))];
+        s.buf >>= len; s.cnt -= len;
+        if (sym < 16) { lens[19 + i++] = (uint8_t)sym; continue; }
+        int prev = 0, rep;
+        if (sym == 16) {
+            if (i == 0) return kErrBadLengths;
+            prev = lens[19 + i - 1];
+            rep = 3 + (int)take(s, 2);
+        } else if (sym == 17) rep = 3 + (int)take(s, 3);
+        else rep = 11 + (int)take(s, 7);
+        if (i + rep > nlen + ndist) return kErrBadLengths;
+        STRK_INF_LOOP
+        while (rep--) lens[19 + i++] = (uint8_t)prev;
+    }
+    if (lens[19 + 256] == 0) return kErrBadLengths;   // no end-of-block code
+    if (!build(lens + 19, nlen, t->lsym, t->lbase, ll)) return kErrBadLengths;
+    if (!build(lens + 19 + nlen, ndist, t->dsym, t->dbase, dl)) return kErrBadLengths;
+    return kErrNone;
+}
+
+STRK_INF_HD int set_fixed(Tables* t, uint8_t* lens, Limits* ll, Limits* dl) {
+    STRK_INF_LOOP
+    for (int i = 0; i < 144; ++i) lens[i] = 8;
+    STRK_INF_LOOP
+    for (int i = 144; i < 256; ++i) lens[i] = 9;
+    STRK_INF_LOOP
+    for (int i = 256; i < 280; ++i) lens[i] = 7;
+    STRK_INF_LOOP
+    for (int i = 280; i < 288; ++i) lens[i] = 8;
+    if (!build(lens, 288, t->lsym, t->lbase, ll)) return kErrBadLengths;
+    STRK_INF_LOOP
+    for (int i = 0; i < 30; ++i) lens[i] = 5;
+    // (the fixed distance code uses 30 of its 32 five-bit codes: build() would call it incomplete)
+    STRK_INF_LOOP
+    for (int i = 30; i < 32; ++i) lens[i] = 5;
+    if (!build(lens, 32, t->dsym, t->dbase, dl)) return kErrBadLengths;
+    return kErrNone;
+}
+
+// Inflates one raw deflate stream of `in_len` bytes into exactly `out_len` bytes.  `in` must be readable up to in_len + 8.
+// `lens`: kLensBytes of scratch.
+STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int out_len, Tables* t, uint8_t* lens) {
+    const uint16_t lbase_tab[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    const uint8_t lext_tab[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    const uint16_t dbase_tab[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
+                                    4097, 6145, 8193, 12289, 16385, 24577};
+    const uint8_t dext_tab[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    Stream s;
+    s.p = in; s.end = in + in_len; s.buf = 0; s.cnt = 0;
+    Limits ll, dl;
+    int pos = 0;
+    bool last = false, in_block = false;
+    int copy_len = 0, copy_dist = 0;
+    for (;;) {
+        if (copy_len > 0) {
+            // a pending match: eight bytes at a time when source and destination do not overlap within them
+            if (copy_dist >= 8 && copy_len >= 8) {
+                uint64_t w;
+                memcpy(&w, out + pos - copy_dist, 8);
+                memcpy(out + pos, &w, 8);
+                pos += 8; copy_len -= 8;
+            } else {
+                out[pos] = out[pos - copy_dist];
+                ++pos; --copy_len;
+            }
+            continue;
+        }
+        if (!in_block) {
+            if (last) break;
+            refill(s);
+            last = take(s, 1) != 0;
+            const int type = (int)take(s, 2);
+            if (type == 0) {
+                // stored: skip to the byte boundary, LEN / NLEN, raw bytes
+                const int drop = s.cnt & 7;
+                s.buf >>= drop; s.cnt -= drop;
+                const uint8_t* q = s.p - (s.cnt >> 3);       // first byte not consumed
+                if (q + 4 > s.end) return kErrStored;
+                const int len = q[0] | (q[1] << 8), nlen = q[2] | (q[3] << 8);
+                if ((len ^ nlen) != 0xffff || q + 4 + len > s.end || pos + len > out_len) return kErrStored;
+                STRK_INF_LOOP
+                for (int i = 0; i < len; ++i) out[pos + i] = q[4 + i];
+                pos += len;
+                s.p = q + 4 + len; s.buf = 0; s.cnt = 0;
+                continue;
+            }
+            int rc;
+            if (type == 1) rc = set_fixed(t, lens, &ll, &dl);
+            else if (type == 2) rc = read_dynamic(s, t, lens, &ll, &dl);
+            else return kErrBadBlockType;
+            if (rc) return rc;
+            in_block = true;
+            continue;
+        }
+        refill(s);
+        if (s.p - 8 > s.end) return kErrOverrun;             // the stream ran past its payload
+        uint32_t v = bitrev15((uint32_t)s.buf);
+        int len = code_len(v, ll);
+        if (len > 15) return kErrBadCode;
+        const int sym = t->lsym[t->lbase[len] + (int)(v >> (15 - len))];
+        s.buf >>= len; s.cnt -= len;
+        if (sym < 256) {
+            if (pos >= out_len) return kErrSize;
+            out[pos++] = (uint8_t)sym;
+            continue;
+        }
+        if (sym == 256) { in_block = false; continue; }
+        if (sym > 285) return kErrBadCode;
+        const int mlen = lbase_tab[sym - 257] + (int)take(s, lext_tab[sym - 257]);
+        v = bitrev15((uint32_t)s.buf);
+        len = code_len(v, dl);
+        if (len > 15) return kErrBadCode;
+        const int dsymv = t->dsym[t->dbase[len] + (int)(v >> (15 - len))];
+        s.buf >>= len; s.cnt -= len;
+        if (dsymv > 29) return kErrBadCode;
+        const int dist = dbase_tab[dsymv] + (int)take(s, dext_tab[dsymv]);
+        if (dist > pos) return kErrBadDistance;
+        if (pos + mlen > out_len) return kErrSize;
+        copy_len = mlen; copy_dist = dist;
+    }
+    return pos == out_len ? kErrNone : kErrSize;
+}
+
+// CRC-32 (gzip) of `n` bytes, byte at a time over a 256-entry table (crc_table: shared, LDS on the device).
+STRK_INF_HD void crc_table_entry(uint32_t* tab, int i) {
+    uint32_t c = (uint32_t)i;
+    STRK_INF_LOOP
+    for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+    tab[i] = c;
+}
+STRK_INF_HD uint32_t crc32_bytes(const uint32_t* tab, const uint8_t* p, int n) {
+    uint32_t c = 0xffffffffu;
+    STRK_INF_LOOP
+    for (int i = 0; i < n; ++i) c = tab[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+    return c ^ 0xffffffffu;
+}
+
+}  // namespace strk_inf

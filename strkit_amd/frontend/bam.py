@@ -177,15 +177,18 @@ def _reg2bin(beg: int, end: int) -> int:
     return 0
 
 
+def bgzf_block(chunk: bytes, body: bytes) -> bytes:
+    """One BGZF block (SAM specification 4.1) around `body`, the raw deflate stream of `chunk` (at most 64 KiB in all)."""
+    bsize = len(body) + 25
+    return struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, bsize) + body + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+
+
 def _bgzf_blocks(data: bytes) -> bytes:
     out = bytearray()
     for i in range(0, len(data), 0xFF00):
         chunk = data[i:i + 0xFF00]
         comp = zlib.compressobj(1, zlib.DEFLATED, -15)
-        body = comp.compress(chunk) + comp.flush()
-        bsize = len(body) + 25
-        out += struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, bsize)
-        out += body + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+        out += bgzf_block(chunk, comp.compress(chunk) + comp.flush())
     return bytes(out) + _BGZF_EOF
 
 

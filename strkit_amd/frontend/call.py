@@ -437,24 +437,26 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = Non
 
     if isinstance(bam, IndexedBam):
         # block-wise access: the records of block k + 1 are inflated (all host cores, outside the GIL) while block k is
-        # being called; memory holds two blocks' worth of the alignment file, never the file
+        # being called; memory holds three blocks' worth of the alignment file, never the file
         from concurrent.futures import ThreadPoolExecutor
         blocks = [b for blk in blocks for b in _one_contig_blocks(blk)]
         tm["load_s"] = tm["load_wait_s"] = 0.0
 
-        def load(block):
+        def load(block, slot):
             t0 = time.perf_counter()
-            reg = bam.region(block[0].contig, min(l.left_flank_coord for l in block), max(l.right_flank_coord for l in block) + 1)
+            reg = bam.region(block[0].contig, min(l.left_flank_coord for l in block), max(l.right_flank_coord for l in block) + 1,
+                             slot=slot)
             return reg, time.perf_counter() - t0
 
         with ThreadPoolExecutor(1) as pool:
-            fut = pool.submit(load, blocks[0]) if blocks else None
+            fut = pool.submit(load, blocks[0], 0) if blocks else None
             for k, block in enumerate(blocks):
                 t0 = time.perf_counter()
                 records, dt = fut.result()
                 tm["load_wait_s"] += time.perf_counter() - t0
                 tm["load_s"] += dt
-                fut = pool.submit(load, blocks[k + 1]) if k + 1 < len(blocks) else None
+                # (three buffers in rotation: the block being called, the one being loaded, and one of slack)
+                fut = pool.submit(load, blocks[k + 1], (k + 1) % 3) if k + 1 < len(blocks) else None
                 safe(block, records)
     else:
         for block in blocks:

@@ -259,8 +259,12 @@ class IndexedBam:
     def references(self) -> list[str]:
         return [c for c, _ in self.contigs]
 
-    def region(self, contig: str, beg: int, end: int, threads: int = 0) -> _Region:
-        """The records that can overlap [beg, end) on `contig` (plus, possibly, a few in front of it)."""
+    def region(self, contig: str, beg: int, end: int, threads: int = 0, slot: int | None = None) -> _Region:
+        """The records that can overlap [beg, end) on `contig` (plus, possibly, a few in front of it).
+        `slot`: the decompressed bytes go into the object's buffer of that number, which is kept and used again by the next
+        region of the same slot — a caller that walks a file block by block (call_blocks: three slots in rotation) then touches
+        fresh memory only while the buffers grow to the size of its largest block; first-touch page faults of a new buffer per
+        block cost more than the inflation itself.  A region of a slot is valid until the next region of that slot."""
         L = _lib.load()
         out = _Region()
         out.contigs = self.contigs
@@ -281,7 +285,12 @@ class IndexedBam:
         # whenever it turns out too small; every piece is scanned once (the scan resumes where the last one stopped)
         glen = max(1, self.contigs[tid][1])
         cap = int(min(1 << 31, max(16 << 20, 4.0 * self.comp.size * (end - beg + 40000) / glen)))
-        buf = np.empty(cap, np.uint8)
+        pool = getattr(self, "_pool", None)
+        if pool is None:
+            pool = self._pool = {}
+        buf = pool.get(slot) if slot is not None else None
+        if buf is None or buf.size < cap:
+            buf = np.empty(cap, np.uint8)
         n = 0                                     # bytes of `buf` that are filled
         parts = []
         keys = ("rec_off", "tid", "pos", "end", "flag", "l_seq", "clip_l", "clip_r")
@@ -318,6 +327,8 @@ class IndexedBam:
         out.n_records = int(len(out.rec_off))
         last = int(out.rec_off[-1]) + 4 + int(struct.unpack_from("<i", buf, int(out.rec_off[-1]))[0]) if out.n_records else 0
         out.data = buf[:max(last, 16)]
+        if slot is not None:
+            pool[slot] = buf
         out._build_index()
         return out
 

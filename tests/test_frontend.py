@@ -468,3 +468,54 @@ def test_mcrl_slr_and_vcf_rows(tmp_path):
     f = body[2].split("\t")
     assert f[1] == str(3074874 - 5 + 1) and f[3] == "CCATG" + "CAG" * 22 and f[8] == "GT:DP:PM:MC:MCRL:SLR"
     assert f[9].split(":")[2:5] == ["dist", "8,9", "7x1|8x10|9x1,8x2|9x12"]
+
+
+def test_device_inflater_code_on_the_host_equals_zlib(tmp_path):
+    """strk_inflate.h (the decoder k_bgzf_inflate runs, one GPU lane per BGZF block) compiled for the host,
+    strk_bgzf_inflate_sw: every block of a synthetic BAM, streams of all three block types (stored, fixed, dynamic codes),
+    a corrupted payload."""
+    import zlib
+    from strkit_amd import _lib
+    from strkit_amd.frontend.bam import bgzf_block
+    t = make_dataset(str(tmp_path), n_loci=12, reads_per_locus=8, read_len=3000, seed=21, sub=0.01, indel=0.01)
+    L = _lib.load()
+    comp = np.fromfile(t["paths"]["bam"], np.uint8)
+    n = L.strk_bgzf_inflate(comp.ctypes.data, comp.size, None, 0, 0)
+    a, b = np.empty(int(n), np.uint8), np.empty(int(n), np.uint8)
+    assert L.strk_bgzf_inflate(comp.ctypes.data, comp.size, a.ctypes.data, a.size, 1) == n
+    assert L.strk_bgzf_inflate_sw(comp.ctypes.data, comp.size, b.ctypes.data, b.size) == n
+    assert np.array_equal(a, b)
+    rng = np.random.default_rng(4)
+    payloads = [b"", b"A", bytes(rng.integers(256, size=40000, dtype=np.uint8)), b"ACGT" * 9000, bytes(60000),
+                bytes(rng.integers(33, 74, size=65000, dtype=np.uint8))]
+    for raw in payloads:
+        for level, strategy in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_FIXED), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_HUFFMAN_ONLY),
+                                (4, zlib.Z_RLE)):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+            body = co.compress(raw) + co.flush()
+            if len(body) + 26 > 65536:
+                continue
+            blk = np.frombuffer(bgzf_block(raw, body), np.uint8)
+            out = np.full(len(raw) + 8, 0xEE, np.uint8)
+            assert L.strk_bgzf_inflate_sw(blk.ctypes.data, blk.size, out.ctypes.data, len(raw)) == len(raw), (len(raw), level, strategy)
+            assert out[:len(raw)].tobytes() == raw and (out[len(raw):] == 0xEE).all()
+    bad = comp.copy()
+    bad[bad.size // 2] ^= 0x21
+    assert L.strk_bgzf_inflate_sw(bad.ctypes.data, bad.size, b.ctypes.data, b.size) < 0 and b"BGZF" in L.strk_last_error()
+
+
+def test_indexed_bam_slots_reuse_their_buffers(tmp_path):
+    """IndexedBam.region(slot=k): the same records as without a slot, in a buffer that the next region of the slot takes over."""
+    from strkit_amd.frontend import IndexedBam
+    from strkit_amd.frontend.synth_large import make_dataset_large
+    t = make_dataset_large(str(tmp_path), n_loci=60, depth=6, read_len=2500, seed=6, spacing=9000, procs=2)
+    ib = IndexedBam(t["paths"]["bam"])
+    spans = [(0, 150000), (150000, 300000), (300000, 540000), (20000, 90000)]
+    plain = [ib.region("chr1", a, b) for a, b in spans]
+    for k, (a, b) in enumerate(spans):
+        reg = ib.region("chr1", a, b, slot=k % 2)
+        assert reg.n_records == plain[k].n_records and np.array_equal(reg.rec_off, plain[k].rec_off)
+        assert np.array_equal(reg.data, plain[k].data) and reg.names(np.arange(min(5, reg.n_records))) == plain[k].names(np.arange(min(5, reg.n_records)))
+        if k >= 2:
+            assert np.shares_memory(reg.data, ib._pool[k % 2])
+    assert set(ib._pool) == {0, 1}

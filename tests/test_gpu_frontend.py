@@ -229,3 +229,40 @@ def test_report_rows_and_vcf_match_the_golden_fixture(gpu_ctx, tmp_path):
     assert set(next(iter(row["reads"].values()))) <= {"s", "cn", "w", "sc", "sl", "realn"}
     cns, w = allele_calling_inputs(row)             # what allele.call_alleles receives (call_locus.py:188-204)
     assert cns.dtype == np.int32 and len(cns) == len(row["reads"]) and abs(w.sum() - 1.0) < 1e-12
+
+
+def test_device_inflater_equals_the_host_one(gpu_ctx, tmp_path):
+    """strk_dbam_inflate (one GPU lane per BGZF block, CRC checked on the device) against strk_bgzf_inflate: a whole file, a
+    stretch from a block boundary with a size limit, a corrupted payload."""
+    import ctypes as C
+    from strkit_amd import _lib
+    from strkit_amd.frontend.synth_large import make_dataset_large
+    t = make_dataset_large(str(tmp_path), n_loci=300, depth=10, read_len=4000, seed=13, spacing=9000, procs=4)
+    L = _lib.load()
+    comp = np.fromfile(t["paths"]["bam"], np.uint8)
+    n = L.strk_bgzf_inflate(comp.ctypes.data, comp.size, None, 0, 0)
+    want = np.empty(int(n), np.uint8)
+    assert L.strk_bgzf_inflate(comp.ctypes.data, comp.size, want.ctypes.data, want.size, 0) == n
+    h = C.c_void_p()
+    _lib.check(L.strk_dbam_open(0, C.byref(h)))
+    try:
+        nxt = C.c_int64(0)
+        assert L.strk_dbam_inflate(h, comp.ctypes.data, comp.size, 0, 1 << 40, C.byref(nxt)) == n and nxt.value == comp.size
+        got = np.empty(int(n), np.uint8)
+        _lib.check(L.strk_dbam_download(h, 0, int(n), got.ctypes.data))
+        assert np.array_equal(got, want)
+        # a stretch: from the third block on, at most 200 000 bytes -> whole blocks only, the next offset is a block start
+        out3 = np.empty(1 << 20, np.uint8)
+        nx = C.c_int64(0)
+        first = L.strk_bgzf_inflate_range(comp.ctypes.data, comp.size, 0, out3.ctypes.data, 140000, C.byref(nx), 1)
+        coff = nx.value
+        m = L.strk_dbam_inflate(h, comp.ctypes.data, comp.size, coff, 200000, C.byref(nxt))
+        assert 0 < m <= 200000 and coff < nxt.value < comp.size
+        part = np.empty(int(m), np.uint8)
+        _lib.check(L.strk_dbam_download(h, 0, int(m), part.ctypes.data))
+        assert np.array_equal(part, want[first:first + m])
+        bad = comp.copy()
+        bad[bad.size // 3] ^= 0x44
+        assert L.strk_dbam_inflate(h, bad.ctypes.data, bad.size, 0, 1 << 40, C.byref(nxt)) < 0 and b"BGZF" in L.strk_last_error()
+    finally:
+        L.strk_dbam_close(h)
