@@ -377,10 +377,16 @@ def extract_reads(bam: NativeBam, rec_idx: np.ndarray, coords: np.ndarray, flank
                                     int(flank_size), int(min_avg_phred), int(wildcard_threshold), status.ctypes.data,
                                     nfl.ctypes.data, ntr.ctypes.data, nfr.ctypes.data, seqs_ptr, cap, seq_off.ctypes.data)
 
-    # size query first: a read may carry an expansion many times the reference window (the flagship case), so the
-    # buffer is sized by what the reads actually hold, not by the locus
-    _lib.check(call(None, 0))
-    cap = int(seq_off[-1]) + 16
+    # A first attempt with room for tracts up to four times the reference window (one pass over the records); a read
+    # may carry an expansion many times that (the flagship case): the library then says how much is needed, nothing is
+    # truncated, and the second call is sized by what the reads actually hold.
+    span = coords[:, 3] - coords[:, 0] if n else np.zeros(0, np.int64)
+    cap = int(np.minimum(bam.l_seq[rec_idx] if hasattr(bam, "l_seq") else span * 4, 4 * span + 64).sum()) + 16
     seqs = np.empty(cap, np.uint8)
-    _lib.check(call(seqs.ctypes.data, cap))
+    rc = call(seqs.ctypes.data, cap)
+    if rc == -12:                                      # STRK_E_NOMEM: seq_off[n] holds the bytes needed
+        cap = int(seq_off[-1]) + 16
+        seqs = np.empty(cap, np.uint8)
+        rc = call(seqs.ctypes.data, cap)
+    _lib.check(rc)
     return {"status": status, "nfl": nfl, "ntr": ntr, "nfr": nfr, "seqs": seqs[:int(seq_off[-1])], "seq_off": seq_off}
