@@ -11,7 +11,10 @@
 //     (limit[L] = left-justified end of the codes of length L; fifteen compares against registers, branch-free), the symbol
 //     is sym[base[L] + (v >> (15 - L))].  Per-lane state: 2 x 15 limits in registers, the sorted symbol arrays and the two
 //     base arrays in a 768-byte slot of LDS (strk_inf::Tables).
-//   * a 64-bit bit buffer refilled with one unaligned 8-byte load per token (the caller pads the input by 8 bytes);
+//   * a 64-bit bit buffer refilled when fewer than 48 bits are left, from eight bytes that were loaded when the previous
+//     refill moved the read position (the caller pads the input by 16 bytes): a refill never waits for memory;
+//   * literals are collected in a register and stored eight at a time (a lane's loads wait for its older stores: the memory
+//     counter retires in order);
 //   * the token loop is a state machine — every iteration a lane either decodes one token or copies up to eight bytes of
 //     a pending match — so that lanes in different states of different streams share one loop body.
 // The same functions compile for the host (tests/test_inflate.py checks them against zlib on every block of a synthetic
@@ -107,17 +110,18 @@ STRK_INF_HD int code_len(uint32_t v, const Limits& lim) {
 
 struct Stream {
     const uint8_t* p;     // next input byte to load
-    const uint8_t* end;   // end of the payload (loads may run up to 8 bytes past it: the caller pads)
+    const uint8_t* end;   // end of the payload (loads may run up to 16 bytes past it: the caller pads)
     uint64_t buf;
+    uint64_t ahead;       // the eight bytes at p, loaded when p last moved: a refill never waits for memory
     int cnt;              // valid bits in buf
 };
 
+STRK_INF_HD void load_ahead(Stream& s) { memcpy(&s.ahead, s.p, 8); }
 STRK_INF_HD void refill(Stream& s) {
-    uint64_t w;
-    memcpy(&w, s.p, 8);
-    s.buf |= w << s.cnt;
+    s.buf |= s.ahead << s.cnt;
     s.p += (63 - s.cnt) >> 3;
     s.cnt |= 56;
+    load_ahead(s);
 }
 STRK_INF_HD uint32_t take(Stream& s, int n) {   // n <= 32 bits, LSB first
     const uint32_t v = (uint32_t)(s.buf & ((1ull << n) - 1));
@@ -188,7 +192,7 @@ STRK_INF_HD int set_fixed(Tables* t, uint8_t* lens, Limits* ll, Limits* dl) {
     return kErrNone;
 }
 
-// Inflates one raw deflate stream of `in_len` bytes into exactly `out_len` bytes.  `in` must be readable up to in_len + 8.
+// Inflates one raw deflate stream of `in_len` bytes into exactly `out_len` bytes.  `in` must be readable up to in_len + 16.
 // `lens`: kLensBytes of scratch.
 STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int out_len, Tables* t, uint8_t* lens) {
     const uint16_t lbase_tab[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -198,18 +202,36 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
     const uint8_t dext_tab[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     Stream s;
     s.p = in; s.end = in + in_len; s.buf = 0; s.cnt = 0;
+    load_ahead(s);
     Limits ll, dl;
-    int pos = 0;
+    int pos = 0;          // bytes written to `out`
+    uint64_t ob = 0;      // literals not yet written: `on` bytes (out[pos .. pos + on)), stored eight at a time
+    int on = 0;
+    auto flush = [&]() {
+        STRK_INF_LOOP
+        for (int i = 0; i < on; ++i) out[pos + i] = (uint8_t)(ob >> (8 * i));
+        pos += on; ob = 0; on = 0;
+    };
     bool last = false, in_block = false;
     int copy_len = 0, copy_dist = 0;
     for (;;) {
         if (copy_len > 0) {
-            // a pending match: eight bytes at a time when source and destination do not overlap within them
-            if (copy_dist >= 8 && copy_len >= 8) {
+            // a pending match, up to eight bytes per iteration whatever its length and distance: the eight bytes at the
+            // source are loaded, a source that overlaps the destination (distance < 8: a run of a short pattern) is
+            // completed by doubling the pattern, and eight bytes are stored even when fewer belong to the match — what
+            // lies behind it is written again by the tokens that follow (never past the end of the block)
+            if (pos + 8 <= out_len) {
                 uint64_t w;
                 memcpy(&w, out + pos - copy_dist, 8);
+                if (copy_dist < 8) {
+                    int have = copy_dist;                      // valid bytes of w
+                    w &= (1ull << (8 * have)) - 1;
+                    STRK_INF_LOOP
+                    while (have < 8) { w |= w << (8 * have); have *= 2; }
+                }
                 memcpy(out + pos, &w, 8);
-                pos += 8; copy_len -= 8;
+                const int n = copy_len < 8 ? copy_len : 8;
+                pos += n; copy_len -= n;
             } else {
                 out[pos] = out[pos - copy_dist];
                 ++pos; --copy_len;
@@ -217,8 +239,9 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
             continue;
         }
         if (!in_block) {
+            flush();
             if (last) break;
-            refill(s);
+            if (s.cnt < 48) refill(s);
             last = take(s, 1) != 0;
             const int type = (int)take(s, 2);
             if (type == 0) {
@@ -233,6 +256,7 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
                 for (int i = 0; i < len; ++i) out[pos + i] = q[4 + i];
                 pos += len;
                 s.p = q + 4 + len; s.buf = 0; s.cnt = 0;
+                load_ahead(s);
                 continue;
             }
             int rc;
@@ -243,19 +267,26 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
             in_block = true;
             continue;
         }
-        refill(s);
-        if (s.p - 8 > s.end) return kErrOverrun;             // the stream ran past its payload
+        if (s.cnt < 48) {
+            refill(s);
+            if (s.p - 8 > s.end) return kErrOverrun;         // the stream ran past its payload
+        }
         uint32_t v = bitrev15((uint32_t)s.buf);
         int len = code_len(v, ll);
         if (len > 15) return kErrBadCode;
         const int sym = t->lsym[t->lbase[len] + (int)(v >> (15 - len))];
         s.buf >>= len; s.cnt -= len;
         if (sym < 256) {
-            if (pos >= out_len) return kErrSize;
-            out[pos++] = (uint8_t)sym;
+            if (pos + on >= out_len) return kErrSize;
+            ob |= (uint64_t)sym << (8 * on);
+            if (++on == 8) {
+                memcpy(out + pos, &ob, 8);
+                pos += 8; ob = 0; on = 0;
+            }
             continue;
         }
         if (sym == 256) { in_block = false; continue; }
+        flush();
         if (sym > 285) return kErrBadCode;
         const int mlen = lbase_tab[sym - 257] + (int)take(s, lext_tab[sym - 257]);
         v = bitrev15((uint32_t)s.buf);
