@@ -66,7 +66,13 @@ typedef struct strk_ctx strk_ctx;
 typedef struct strk_params {
     int32_t max_iters;          /* rc_params.max_iters                (params.py:45  -> 50) */
     int32_t local_search_range; /* rc_params.initial_local_search_range (params.py:26 -> 3) */
-    int32_t step_size;          /* rc_params.initial_step_size          (params.py:27 -> 1) */
+    int32_t step_size;          /* rc_params.initial_step_size          (params.py:27 -> 1)
+                                   The reference calls both INITIAL values that "can be narrowed within the
+                                   get_repeat_count fn" (repeat_count_params.py:14); that function is in the un-vendored
+                                   Rust crate, so here they stay fixed for the whole search, as in the in-tree sibling
+                                   get_ref_repeat_count (repeats.py:100-151): a third unpinned choice next to tie_rule
+                                   and end_flags; a different schedule would change
+                                   search_replay() only, the score table is schedule-independent. */
     int32_t tie_rule;           /* STRK_TIE_FIRST */
     int32_t end_flags;          /* STRK_SG_ALL */
     int32_t feedback;           /* 1: start-count feedback across the reads of a locus

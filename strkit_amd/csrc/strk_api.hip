@@ -3,9 +3,12 @@
 // anonymous namespace: strk_host_miss.inc (window-miss rounds), strk_host_ref.inc (reference side),
 // strk_host_realign.inc (realignment).  strk_frontend.h holds the CPU-only record scan / read extraction.
 //
+// strk_dbam.inc (spliced in at the end) holds the device-side BGZF inflater.
+//
 // One context = one HIP device.  A batched call enqueues, on the caller's stream:
-//   memset(counters) -> k_plan -> k_dp<class> x 13 -> k_dp_generic -> k_replay -> counters D2H
-// and synchronises once.  Only when a read's search left its speculative candidate window (rare;
+//   memset(counters) -> k_hash -> k_plan -> k_dp_band -> k_dp_band_wide -> k_dp_all -> k_dp_long -> k_dp_generic -> k_replay
+//   -> counters D2H
+// (strk_submit_loci_device) and is completed by strk_finish, which synchronises once.  Only when a read's search left its speculative candidate window (rare;
 // strk_stats.n_miss_reads) does the host run extra rounds: re-score the wanted window on the
 // device, replay that locus on the host with the same search_replay() the device uses.
 #include <hip/hip_runtime.h>
