@@ -160,3 +160,31 @@ def test_reads_with_more_than_eight_symbol_classes_are_searched_on_the_generic_t
             got, st = _run(b, gpu_ctx, max_iters=7, lsr=1, feedback=feedback, band=band)
             assert st["n_fallback"] == 2
             _compare(b, got, oracle_count(b, 7, 1, 1, 0, 15, feedback))
+
+
+@pytest.mark.parametrize("flags", list(range(16)))
+def test_band_kernel_under_every_end_flag_mode(gpu_ctx, flags):
+    """The banded first pass carries the two free boundaries as table content (pad bytes of the row words, the "no row"
+    symbol's word) and hands the boundary value in at one step per pass: every combination of the four end-gap flags, on
+    clean and on lightly mutated reads, must give the oracle's answers with the band doing the work; reads whose band
+    meets column 0 / row 0 at different steps share a wave (short and long left flanks, small and large copy numbers)."""
+    rng = np.random.default_rng(100 + flags)
+    loci = []
+    for k in range(24):
+        motif, reads = random_locus(rng, 5, motif_len=(1, 6), cn=(2, 45), flank=((10, 70) if k % 3 else (60, 110)), edits=(0, 2))
+        loci.append((motif, reads))
+    b = LocusBatch.from_reads(loci)
+    exp = oracle_count(b, flags=flags)
+    from strkit_amd import _lib
+    ctx = _lib.Context(0)      # a context of its own: the band of a shared one may be in a cool-down after noisy batches
+    try:
+        got, st = _run(b, ctx, end_flags=flags)
+        _compare(b, got, exp)
+        assert st["n_band_reads"] >= b.n_reads // 2, st
+        got0, st0 = _run(b, ctx, end_flags=flags, band=False)
+        _compare(b, got0, exp)
+        assert st0["n_band_reads"] == 0
+        if flags == 15:
+            assert st["n_band_fallback"] <= st["n_band_reads"] // 3, st
+    finally:
+        ctx.close()
