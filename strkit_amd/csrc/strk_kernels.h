@@ -299,12 +299,12 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
         if (s_bytes_exact) atomicAdd(a.cells + 3, s_bytes_exact);
     }
     __syncthreads();
-    // Band items of a block are listed in the order of (band class, motif length, prefix rows): the band kernel runs the
-    // 8 (4, 2, 1) items of a chunk in lock-step for as many steps as the longest one needs, and items with the same motif
-    // length and row count have their fork rows at the same steps.  rank = items of this block that sort before mine.
+    // Band items of a block are listed in the order of (band class, prefix rows): the band kernel runs the 8 (4, 2, 1) items of
+    // a chunk in lock-step for as many steps as the longest one needs (chunks of a 256-read block in arrival order: 8.5 % more
+    // steps than the items need; sorted by rows: 4 %).  rank = items of this block that sort before mine.
     int band_rank = 0;
     {
-        const unsigned long long mine = band_list >= 0 ? ((unsigned long long)(band_list - kBandClass0) << 60) | ((unsigned long long)m << 40) |
+        const unsigned long long mine = band_list >= 0 ? ((unsigned long long)(band_list - kBandClass0) << 60) |
                                                            ((unsigned long long)(nfl + (lo + n - 1) * m) << 10) | threadIdx.x
                                                        : ~0ull;
         s_key[threadIdx.x] = mine;
