@@ -7,7 +7,7 @@ TAG=${1:-bench}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="bench.py --no-cpu-baseline --no-extras --no-e2e --steps 16 --warmup 4"
+ARGS="bench.py --no-cpu-baseline --no-extras --no-e2e --steps 16 --warmup 4 $EXTRA"   # EXTRA: e.g. "--config 3"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o b -- python3 $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_p1 -o b -- python3 $ARGS --pipeline 1 > $OUT/trace_p1.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU"; do
