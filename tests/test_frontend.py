@@ -519,3 +519,25 @@ def test_indexed_bam_slots_reuse_their_buffers(tmp_path):
         if k >= 2:
             assert np.shares_memory(reg.data, ib._pool[k % 2])
     assert set(ib._pool) == {0, 1}
+
+
+def test_fasta_loader_handles_line_shapes(tmp_path):
+    """Fixed-width lines take the strided path, anything else the masked one; case is kept (soft-masked references,
+    docs/output_formats.md:96); contigs are matched with or without the chr prefix."""
+    from strkit_amd.frontend.fasta import write_fasta
+    rng = np.random.default_rng(12)
+    seqs = {"chr1": "".join("ACGTacgtN"[i] for i in rng.integers(9, size=100_003)), "chr2": "ACGT" * 15, "chrEmptyTail": "A" * 60}
+    p = str(tmp_path / "a.fa")
+    write_fasta(p, seqs, width=60)
+    f = Fasta(p)
+    assert f.references == list(seqs) and all(f.fetch(k, 0, len(v) + 5) == v for k, v in seqs.items())
+    assert f.get_reference_length("chr1") == 100_003 and f.fetch("1", 59, 62) == seqs["chr1"][59:62] and f.array("chr2").tobytes() == seqs["chr2"].encode()
+    odd = str(tmp_path / "odd.fa")
+    with open(odd, "w", newline="") as fh:
+        fh.write(">a some description\nACGT\nAC\n\n>b\r\nAC GT\r\nTT\r\n>c\nACGTACGTAC\nACGTACGTAC\nACG")
+    g = Fasta(odd)
+    assert {k: g.fetch(k, 0, 100) for k in g.references} == {"a": "ACGTAC", "b": "ACGTTT", "c": "ACGTACGTACACGTACGTACACG"}
+    with pytest.raises(KeyError):
+        g.fetch("nope", 0, 1)
+    with pytest.raises(IndexError):
+        g.fetch("a", 7, 9)
