@@ -405,6 +405,22 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = Non
     n_depth = 0
     tm = {"ref_side_s": 0.0, "realign_s": 0.0, "extract_s": 0.0, "count_s": 0.0, "errors": []}
 
+    # block-wise access: the first block's records are being inflated while the reference side is computed
+    pool = fut = None
+    if isinstance(bam, IndexedBam):
+        from concurrent.futures import ThreadPoolExecutor
+        blocks = [b for blk in blocks for b in _one_contig_blocks(blk)]
+        tm["load_s"] = tm["load_wait_s"] = 0.0
+
+        def load(block, slot):
+            t0 = time.perf_counter()
+            reg = bam.region(block[0].contig, min(l.left_flank_coord for l in block), max(l.right_flank_coord for l in block) + 1,
+                             slot=slot)
+            return reg, time.perf_counter() - t0
+
+        pool = ThreadPoolExecutor(1)
+        fut = pool.submit(load, blocks[0], 0) if blocks else None
+
     # reference side of ALL loci first, a few thousand per library call (each of its lock-step rounds is one device launch
     # however many loci take part); a chunk that fails is left to the per-block path below, which isolates the locus
     ref_cache: dict[int, dict | None] = {}
@@ -435,21 +451,10 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = Non
         results.extend(rows)
         n_depth += n
 
-    if isinstance(bam, IndexedBam):
+    if pool is not None:
         # block-wise access: the records of block k + 1 are inflated (all host cores, outside the GIL) while block k is
         # being called; memory holds three blocks' worth of the alignment file, never the file
-        from concurrent.futures import ThreadPoolExecutor
-        blocks = [b for blk in blocks for b in _one_contig_blocks(blk)]
-        tm["load_s"] = tm["load_wait_s"] = 0.0
-
-        def load(block, slot):
-            t0 = time.perf_counter()
-            reg = bam.region(block[0].contig, min(l.left_flank_coord for l in block), max(l.right_flank_coord for l in block) + 1,
-                             slot=slot)
-            return reg, time.perf_counter() - t0
-
-        with ThreadPoolExecutor(1) as pool:
-            fut = pool.submit(load, blocks[0], 0) if blocks else None
+        try:
             for k, block in enumerate(blocks):
                 t0 = time.perf_counter()
                 records, dt = fut.result()
@@ -458,6 +463,8 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = Non
                 # (three buffers in rotation: the block being called, the one being loaded, and one of slack)
                 fut = pool.submit(load, blocks[k + 1], (k + 1) % 3) if k + 1 < len(blocks) else None
                 safe(block, records)
+        finally:
+            pool.shutdown(wait=True)
     else:
         for block in blocks:
             safe(block, bam)
