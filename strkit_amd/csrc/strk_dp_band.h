@@ -9,18 +9,19 @@ namespace strk {
 // DIAGONALS instead of columns: lane l of a group keeps the 16 diagonals d = dlo + 16 l .. + 15 of the
 // current row, so a group of 8 (16) lanes covers a band of 128 (256) diagonals that follows the
 // alignment down the matrix.  Per row and slot k:
-//     up   = (r-1, j)   = old[k+1]   (the next lane's old[0] for k = 15: a second DPP, mid-step)
+//     up   = (r-1, j)   = old[k+1]   (the next lane's NEW [0] for k = 15: it works one row behind; a DPP, mid-step)
 //     left = (r, j-1)   = new[k-1]   (the previous lane's new[15] for k = 0: the systolic skew)
 //     diag = (r-1, j-1) = old[k] + w
 // and the selector bytes of the lane's 16 columns slide by one column per row (four v_alignbyte plus
-// one LDS byte).  Cells outside the band are 0 in G-space (= -inf: every real value is >= 0), cells
-// left of column 1 carry the left-boundary value, cells right of the last column replicate it.
+// one LDS byte).  Cells outside the band are 0 in G-space (= -inf: every real value is >= 0); the pad columns
+// left of column 1 and the rows in front of row 1 carry the boundary values by themselves (row-word tables below),
+// cells right of the last column replicate it.
 // The backward pass is the same function on the reversed right flank and the reversed window.
 // ---------------------------------------------------------------------------------------------
 struct BandLayout {
-    // class-byte array: selb[pad + x] <-> db[x]; `pad` selector-0x0c bytes in front and pad + kBandHiPad
+    // class-byte array: selb[pad + x] <-> db[x]; `pad` pad selectors in front and up to pad + kBandHiPad
     // behind, sized so that no column the two passes can ask for (virtual rows, rows beyond |db|, the
-    // two-step prefetch) falls outside it: the hot loop indexes it without clamping.
+    // prefetch) falls outside it: the hot loop indexes it without clamping.
     int wd, pad, maxdb, maxcol, off_sel, off_cp, off_ct, off_b0, group_bytes, sel_len;
     static constexpr int OFF_COMB = 0, OFF_MISC = OFF_COMB + kTableMax * 4, OFF_LMAX = OFF_MISC + 16;
     static constexpr int kBandHiPad = kBandRowSlack + 32;
