@@ -32,8 +32,10 @@
 // compiler's post-RA scheduler crashes on what -O3 makes of them when it tries).
 #if defined(__clang__)
 #define STRK_INF_LOOP _Pragma("clang loop vectorize(disable) interleave(disable)")
+#define STRK_INF_UNROLL _Pragma("unroll")
 #else
 #define STRK_INF_LOOP
+#define STRK_INF_UNROLL
 #endif
 
 namespace strk_inf {
@@ -214,13 +216,35 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
     };
     bool last = false, in_block = false;
     int copy_len = 0, copy_dist = 0;
+    // Every round of the outer loop a lane (1) finishes its pending match, (2) decodes literals up to the next match or the
+    // end of the deflate block, (3) decodes that match.  The lanes of a wave run the three phases together (each phase lasts
+    // as long as the slowest lane needs): a loop whose every iteration offers all the token kinds would make every lane pay
+    // for every kind, every time.
     for (;;) {
-        if (copy_len > 0) {
-            // a pending match, up to eight bytes per iteration whatever its length and distance: the eight bytes at the
-            // source are loaded, a source that overlaps the destination (distance < 8: a run of a short pattern) is
-            // completed by doubling the pattern, and eight bytes are stored even when fewer belong to the match — what
-            // lies behind it is written again by the tokens that follow (never past the end of the block)
-            if (pos + 8 <= out_len) {
+        while (copy_len > 0) {
+            // up to 32 bytes per iteration when the source lies at least that far back, else eight whatever the match's
+            // length and distance: the bytes at the source are loaded, a source that overlaps the destination (distance < 8:
+            // a run of a short pattern) is completed by doubling the pattern, and whole words are stored even when fewer
+            // bytes belong to the match — what lies behind it is written again by the tokens that follow (never past the
+            // end of the block)
+            if (copy_dist >= 128 && copy_len > 32 && pos + 128 <= out_len) {
+                // (a long match: sixteen loads in flight, one trip to memory for 128 bytes)
+                uint64_t w[16];
+                const uint8_t* src = out + pos - copy_dist;
+                STRK_INF_UNROLL
+                for (int k = 0; k < 16; ++k) memcpy(&w[k], src + 8 * k, 8);
+                STRK_INF_UNROLL
+                for (int k = 0; k < 16; ++k) memcpy(out + pos + 8 * k, &w[k], 8);
+                const int n = copy_len < 128 ? copy_len : 128;
+                pos += n; copy_len -= n;
+            } else if (copy_dist >= 32 && copy_len > 8 && pos + 32 <= out_len) {
+                uint64_t w0, w1, w2, w3;
+                const uint8_t* src = out + pos - copy_dist;
+                memcpy(&w0, src, 8); memcpy(&w1, src + 8, 8); memcpy(&w2, src + 16, 8); memcpy(&w3, src + 24, 8);
+                memcpy(out + pos, &w0, 8); memcpy(out + pos + 8, &w1, 8); memcpy(out + pos + 16, &w2, 8); memcpy(out + pos + 24, &w3, 8);
+                const int n = copy_len < 32 ? copy_len : 32;
+                pos += n; copy_len -= n;
+            } else if (pos + 8 <= out_len) {
                 uint64_t w;
                 memcpy(&w, out + pos - copy_dist, 8);
                 if (copy_dist < 8) {
@@ -236,7 +260,6 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
                 out[pos] = out[pos - copy_dist];
                 ++pos; --copy_len;
             }
-            continue;
         }
         if (!in_block) {
             flush();
@@ -267,23 +290,25 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
             in_block = true;
             continue;
         }
-        if (s.cnt < 48) {
-            refill(s);
-            if (s.p - 8 > s.end) return kErrOverrun;         // the stream ran past its payload
-        }
-        uint32_t v = bitrev15((uint32_t)s.buf);
-        int len = code_len(v, ll);
-        if (len > 15) return kErrBadCode;
-        const int sym = t->lsym[t->lbase[len] + (int)(v >> (15 - len))];
-        s.buf >>= len; s.cnt -= len;
-        if (sym < 256) {
+        int sym, len;
+        uint32_t v;
+        for (;;) {
+            if (s.cnt < 48) {
+                refill(s);
+                if (s.p - 8 > s.end) return kErrOverrun;     // the stream ran past its payload
+            }
+            v = bitrev15((uint32_t)s.buf);
+            len = code_len(v, ll);
+            if (len > 15) return kErrBadCode;
+            sym = t->lsym[t->lbase[len] + (int)(v >> (15 - len))];
+            s.buf >>= len; s.cnt -= len;
+            if (sym >= 256) break;
             if (pos + on >= out_len) return kErrSize;
             ob |= (uint64_t)sym << (8 * on);
             if (++on == 8) {
                 memcpy(out + pos, &ob, 8);
                 pos += 8; ob = 0; on = 0;
             }
-            continue;
         }
         if (sym == 256) { in_block = false; continue; }
         flush();
