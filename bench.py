@@ -123,35 +123,46 @@ def pmc_summary(kernel: str) -> dict | None:
 
 
 def run_e2e(data: dict) -> dict:
-    """`python -m strkit_amd call` on files: alignment file (block-wise through its .bai) + reference + catalog -> per-read copy
-    numbers, every stage timed.  calling_s = everything but reading the files (reference side, read extraction, counting,
-    filtering); report_s = building the per-read report rows."""
+    """`python -m strkit_amd call` on files: alignment file + reference + catalog -> per-read copy numbers, every stage timed,
+    with the device front end (the file inflated, scanned and cut on the GPU: the default without --realign) and with the host
+    one (block-wise through the .bai on the host cores).  calling_s = reference side + read extraction + counting + filtering;
+    report_s = building the per-read report rows; open_s = opening the alignment file (device: upload, inflation and record
+    scan of the whole file)."""
     import shutil
     from strkit_amd.frontend import call_sample
     paths = data["paths"]
     warm = os.path.join(data["dir"], "warm.bed")
     with open(paths["loci"]) as fh, open(warm, "w") as out:
         out.writelines(fh.readlines()[:200])
-    call_sample(paths["bam"], paths["ref"], warm)            # workspace allocation, library warm-up
-    t0 = time.perf_counter()
-    rep = call_sample(paths["bam"], paths["ref"], paths["loci"])
-    wall = time.perf_counter() - t0
-    st = rep["stage_times"]
     truth = {(int(l), int(r)): int(c) for l, r, c in data["truth"]}
-    n_reads = n_true = 0
-    for row in rep["results"]:
-        for name, rd in row.get("reads", {}).items():
-            l, r = name[1:].split("_r")
-            n_reads += 1
-            n_true += rd["cn"] == truth[(int(l), int(r))]
-    calling = sum(st.get(k, 0.0) for k in ("ref_side_s", "realign_s", "extract_s", "count_s"))
-    out = {"loci": len(rep["results"]), "reads": n_reads, "read_len": int(data.get("read_len", 0)) or None,
-           "bam_mb": os.path.getsize(paths["bam"]) >> 20, "wall_s": wall, "loci_per_s": len(rep["results"]) / wall,
-           "reads_per_s": n_reads / wall, "calling_s": calling, "stage_s": st,
-           "device_share_of_calling": (st.get("count_device_s", 0.0)) / max(calling, 1e-9),
-           "reads_with_true_allele_cn": n_true, "dataset_gen_s": data["gen_s"],
-           "note": "wall_s = open + index + FASTA + catalog + calling + report rows; load_s (BGZF inflate of the block's records, all "
-                   "cores) runs in a second thread and overlaps calling, load_wait_s is what the caller waited for it"}
+
+    def one(front_end):
+        call_sample(paths["bam"], paths["ref"], warm, front_end=front_end)      # workspace allocation, library warm-up
+        t0 = time.perf_counter()
+        rep = call_sample(paths["bam"], paths["ref"], paths["loci"], front_end=front_end)
+        wall = time.perf_counter() - t0
+        st = rep["stage_times"]
+        n_reads = n_true = 0
+        for row in rep["results"]:
+            for name, rd in row.get("reads", {}).items():
+                l, r = name[1:].split("_r")
+                n_reads += 1
+                n_true += rd["cn"] == truth[(int(l), int(r))]
+        calling = sum(st.get(k, 0.0) for k in ("ref_side_s", "realign_s", "extract_s", "count_s"))
+        return {"loci": len(rep["results"]), "reads": n_reads, "wall_s": wall, "loci_per_s": len(rep["results"]) / wall,
+                "reads_per_s": n_reads / wall, "calling_s": calling, "stage_s": st,
+                "device_share_of_calling": (st.get("count_device_s", 0.0)) / max(calling, 1e-9),
+                "reads_with_true_allele_cn": n_true}, rep["results"]
+
+    dev, rows_dev = one("device")
+    host, rows_host = one("host")
+    out = dict(dev)
+    out.update({"read_len": int(data.get("read_len", 0)) or None, "bam_mb": os.path.getsize(paths["bam"]) >> 20,
+                "host_front_end": host, "front_ends_agree": rows_dev == rows_host, "dataset_gen_s": data["gen_s"],
+                "note": "wall_s = opening the alignment file + FASTA + catalog + calling + report rows.  Device front end: open_s = "
+                        "upload + inflation + record scan of the whole file on the GPU, the bases never leave it.  Host front end: load_s "
+                        "(BGZF inflate of a block's records, all cores) runs in a second thread and overlaps calling, load_wait_s is what "
+                        "the caller waited for it"})
     shutil.rmtree(data["dir"], ignore_errors=True)
     return out
 

@@ -271,8 +271,30 @@ void strk_dbam_close(strk_dbam* d);
 int64_t strk_dbam_inflate(strk_dbam* d, const uint8_t* comp, int64_t n_comp, int64_t coff, int64_t max_out, int64_t* next_coff);
 /* bytes [off, off + n) of the decompressed stream -> host (headers, a single record for realignment, tests) */
 int strk_dbam_download(strk_dbam* d, int64_t off, int64_t n, uint8_t* out);
+/* the first n bytes of the bases of the last strk_dbam_extract -> host (tests) */
+int strk_dbam_download_seqs(strk_dbam* d, int64_t n, uint8_t* out);
 /* device address and size of the decompressed stream (valid until the next strk_dbam_inflate / strk_dbam_close) */
 void* strk_dbam_data(strk_dbam* d, int64_t* n_bytes);
+/* BAM virtual offsets (block offset << 16 | offset in the block) -> offsets in the decompressed stream (-1: not in it) */
+int strk_dbam_voffsets(strk_dbam* d, const uint64_t* voff, int64_t n, int64_t* out);
+/* strk_bam_scan on the device.  `starts`: ascending, distinct offsets of record starts (the first record and what the .bai
+ * linear index points at); one GPU lane walks the record chain from each to the next.  Returns the number of records; the
+ * host arrays (capacity cap) are filled, in stream order, when it fits. */
+int64_t strk_dbam_scan(strk_dbam* d, const int64_t* starts, int64_t n_starts, int64_t cap, int64_t* rec_off, int32_t* tid,
+                       int32_t* pos, int32_t* end, int32_t* flag, int32_t* l_seq, int32_t* clip_l, int32_t* clip_r, int32_t* l_name);
+/* strk_extract_reads on the device (no substitute CIGARs): the bases stay in HBM (*d_seqs, valid until the next call on the
+ * object), status / lengths / seq_off and the name length of every item come back. */
+int strk_dbam_extract(strk_dbam* d, int32_t n_items, const int64_t* rec_off, const int64_t* coords, int32_t flank_size,
+                      int32_t min_avg_phred, int32_t wildcard_threshold, int32_t* status, int32_t* nfl, int32_t* ntr, int32_t* nfr,
+                      int64_t* seq_off, int32_t* name_len, void** d_seqs);
+/* read names of n records into out[0 .. out_off[n]); out_off = running sum of the name lengths (input) */
+int strk_dbam_names(strk_dbam* d, int64_t n, const int64_t* rec_off, const int64_t* out_off, uint8_t* out);
+/* strk_count_loci with the bases already on the device (d_seqs; batch->seqs is ignored), everything else on the host */
+int strk_count_loci_dseqs(strk_ctx* ctx, const strk_batch* batch, const void* d_seqs, const strk_params* params, int32_t* out_cn,
+                          int32_t* out_score, int32_t* out_n_iters, int32_t* out_start, strk_stats* stats);
+/* test aid: the two statements of the CIGAR -> locus boundaries walk on one alignment (bit 0: run index, bit 1: one pass) */
+int strk_read_coords_both(const uint32_t* cigar, int32_t n_cigar, int64_t start, const int64_t* coords, int64_t* out_runs,
+                          int64_t* out_linear);
 /* strk_bgzf_inflate's contract, served by the DEVICE inflater's code compiled for the host, one thread (test aid) */
 int64_t strk_bgzf_inflate_sw(const uint8_t* comp, int64_t n_comp, uint8_t* out, int64_t out_cap);
 

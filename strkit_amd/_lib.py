@@ -48,7 +48,8 @@ EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk
            "strk_count_loci_device", "strk_submit_loci_device", "strk_finish", "strk_score_table",
            "strk_score_ref_table", "strk_ref_repeat_count", "strk_ref_repeat_count_batch", "strk_realign", "strk_bam_scan",
            "strk_extract_reads", "strk_bgzf_inflate", "strk_bgzf_inflate_range", "strk_bam_names", "strk_bam_scan_piece",
-           "strk_dbam_open", "strk_dbam_close", "strk_dbam_inflate", "strk_dbam_download", "strk_dbam_data", "strk_bgzf_inflate_sw")
+           "strk_dbam_open", "strk_dbam_close", "strk_dbam_inflate", "strk_dbam_download", "strk_dbam_data", "strk_bgzf_inflate_sw",
+           "strk_dbam_download_seqs", "strk_dbam_voffsets", "strk_dbam_scan", "strk_dbam_extract", "strk_dbam_names", "strk_count_loci_dseqs", "strk_read_coords_both")
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -129,6 +130,21 @@ def load(build: bool = True):
         L.strk_dbam_download.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.strk_dbam_data.restype = C.c_void_p
         L.strk_dbam_data.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.strk_dbam_download_seqs.restype = C.c_int
+        L.strk_dbam_download_seqs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.strk_dbam_voffsets.restype = C.c_int
+        L.strk_dbam_voffsets.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.strk_dbam_scan.restype = C.c_int64
+        L.strk_dbam_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 9
+        L.strk_dbam_extract.restype = C.c_int
+        L.strk_dbam_extract.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6 + [C.POINTER(C.c_void_p)]
+        L.strk_dbam_names.restype = C.c_int
+        L.strk_dbam_names.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.strk_count_loci_dseqs.restype = C.c_int
+        L.strk_count_loci_dseqs.argtypes = ([C.c_void_p, C.POINTER(StrkBatch), C.c_void_p, C.POINTER(StrkParams)] + [C.c_void_p] * 4
+                                            + [C.POINTER(StrkStats)])
+        L.strk_read_coords_both.restype = C.c_int
+        L.strk_read_coords_both.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.strk_bgzf_inflate_sw.restype = C.c_int64
         L.strk_bgzf_inflate_sw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.strk_bam_scan_piece.restype = C.c_int64

@@ -55,8 +55,13 @@ def count_loci(b: LocusBatch, rc_params: RepeatCountParams | None = None, feedba
     n = max(b.n_reads, 1)
     out = {k: np.zeros(n, np.int32) for k in ("cn", "score", "n_iters", "start")}
     st = _lib.StrkStats()
-    rc = _lib.load().strk_count_loci(ctx.handle, C.byref(s), C.byref(p), _ptr(out["cn"]), _ptr(out["score"]),
-                                     _ptr(out["n_iters"]), _ptr(out["start"]), C.byref(st))
+    d_seqs = getattr(b, "d_seqs", None)      # the bases are in device memory already (frontend.native.DeviceBam)
+    if d_seqs:
+        rc = _lib.load().strk_count_loci_dseqs(ctx.handle, C.byref(s), C.c_void_p(d_seqs), C.byref(p), _ptr(out["cn"]), _ptr(out["score"]),
+                                               _ptr(out["n_iters"]), _ptr(out["start"]), C.byref(st))
+    else:
+        rc = _lib.load().strk_count_loci(ctx.handle, C.byref(s), C.byref(p), _ptr(out["cn"]), _ptr(out["score"]),
+                                         _ptr(out["n_iters"]), _ptr(out["start"]), C.byref(st))
     del keep
     if rc == _lib.STRK_E_EMPTY:
         raise ValueError("max() arg is an empty sequence")  # what the reference's max() raises

@@ -444,7 +444,8 @@ int count_device(strk_ctx* c, const strk_batch* b, const strk_params* params, in
 }
 
 // uploads a host batch into the context's staging buffers; returns a batch of device pointers
-int upload_batch(strk_ctx* c, const strk_batch* b, strk_batch* d, hipStream_t st) {
+// `d_seqs` (optional): the bases are in device memory already (strk_dbam_extract); b->seqs is not read then
+int upload_batch(strk_ctx* c, const strk_batch* b, strk_batch* d, hipStream_t st, const uint8_t* d_seqs = nullptr) {
     if (!b || b->n_reads < 0 || b->n_loci < 0) return fail(STRK_E_INVALID, "bad batch");
     *d = *b;
     if (b->n_reads == 0 || b->n_loci == 0) return 0;
@@ -462,14 +463,15 @@ int upload_batch(strk_ctx* c, const strk_batch* b, strk_batch* d, hipStream_t st
             return fail(STRK_E_INVALID, "read %zu: seq_off does not match nfl+ntr+nfr", r);
     }
     const size_t nbases = (size_t)b->seq_off[nr], nmot = (size_t)b->motif_off[nl];
-    if (nbases && !b->seqs) return fail(STRK_E_INVALID, "seqs is NULL");
+    if (nbases && !b->seqs && !d_seqs) return fail(STRK_E_INVALID, "seqs is NULL");
     HIP_TRY(hipSetDevice(c->device));
     int rc;
 #define UP(buf, src, bytes, field)                                                              \
     if ((rc = c->buf.ensure(std::max<size_t>((bytes), 16)))) return rc;                         \
     if ((bytes) > 0) HIP_TRY(hipMemcpyAsync(c->buf.p, (src), (bytes), hipMemcpyHostToDevice, st)); \
     d->field = static_cast<decltype(d->field)>(c->buf.p);
-    UP(in_seqs, b->seqs, nbases, seqs)
+    if (d_seqs) d->seqs = d_seqs;
+    else { UP(in_seqs, b->seqs, nbases, seqs) }
     UP(in_seq_off, b->seq_off, (nr + 1) * 8, seq_off)
     UP(in_nfl, b->nfl, nr * 4, nfl)
     UP(in_ntr, b->ntr, nr * 4, ntr)
@@ -630,11 +632,16 @@ int strk_finish(strk_ctx* ctx, strk_stats* stats) {
 
 int strk_count_loci(strk_ctx* ctx, const strk_batch* batch, const strk_params* params, int32_t* out_cn,
                     int32_t* out_score, int32_t* out_n_iters, int32_t* out_start, strk_stats* stats) {
+    return strk_count_loci_dseqs(ctx, batch, nullptr, params, out_cn, out_score, out_n_iters, out_start, stats);
+}
+
+int strk_count_loci_dseqs(strk_ctx* ctx, const strk_batch* batch, const void* d_seqs, const strk_params* params, int32_t* out_cn,
+                          int32_t* out_score, int32_t* out_n_iters, int32_t* out_start, strk_stats* stats) {
     if (!ctx) return fail(STRK_E_INVALID, "ctx is NULL");
     if (stats) memset(stats, 0, sizeof *stats);
     strk_batch d;
     int rc;
-    if ((rc = upload_batch(ctx, batch, &d, nullptr))) return rc;
+    if ((rc = upload_batch(ctx, batch, &d, nullptr, static_cast<const uint8_t*>(d_seqs)))) return rc;
     if (batch->n_reads == 0 || batch->n_loci == 0) return 0;
     if (!batch->est_cn) return fail(STRK_E_INVALID, "est_cn is NULL");
     const size_t nb = (size_t)batch->n_reads * 4;

@@ -14,80 +14,9 @@
 
 #include <zlib.h>
 
+#include "strk_bamrec.h"
+
 namespace strk_fe {
-
-inline int32_t rd_i32(const uint8_t* p) { int32_t v; memcpy(&v, p, 4); return v; }
-inline uint32_t rd_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
-inline uint16_t rd_u16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
-
-constexpr bool consumes_query(uint32_t op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
-constexpr bool consumes_ref(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
-constexpr bool is_aligned(uint32_t op) { return op == 0 || op == 7 || op == 8; }
-
-// Fixed part of a BAM alignment record (after block_size): refID, pos, l_read_name, mapq, bin, n_cigar_op, flag,
-// l_seq, next_refID, next_pos, tlen = 32 bytes, then read_name, cigar, seq (4 bit), qual.
-struct Rec {
-    int32_t tid, pos, l_name, n_cigar, flag, l_seq;   // n_cigar / cigar: the real CIGAR (from the CG tag when the record holds the long-CIGAR placeholder)
-    const uint8_t* name;
-    const uint8_t* cigar;
-    const uint8_t* seq;
-    const uint8_t* qual;
-};
-inline bool parse_rec(const uint8_t* buf, int64_t n_bytes, int64_t off, Rec* r, int64_t* next) {
-    if (off + 4 > n_bytes) return false;
-    const int32_t block = rd_i32(buf + off);
-    if (block < 32 || off + 4 + block > n_bytes) return false;
-    const uint8_t* p = buf + off + 4;
-    r->tid = rd_i32(p);
-    r->pos = rd_i32(p + 4);
-    r->l_name = p[8];
-    r->n_cigar = rd_u16(p + 12);
-    r->flag = rd_u16(p + 14);
-    r->l_seq = rd_i32(p + 16);
-    const int64_t need = 32 + (int64_t)r->l_name + 4 * (int64_t)r->n_cigar + (r->l_seq + 1) / 2 + r->l_seq;
-    if (r->l_seq < 0 || need > block) return false;
-    r->name = p + 32;
-    r->cigar = r->name + r->l_name;
-    r->seq = r->cigar + 4 * (size_t)r->n_cigar;
-    r->qual = r->seq + (r->l_seq + 1) / 2;
-    *next = off + 4 + block;
-    // Alignments with more than 65 535 CIGAR operations (ultralong reads) store the placeholder <l_seq>S<ref_len>N
-    // and the real CIGAR in the tag CG:B,I (SAM specification, section 4.2.2).
-    if (r->n_cigar == 2 && r->l_seq > 0) {
-        const uint32_t c0 = rd_u32(r->cigar), c1 = rd_u32(r->cigar + 4);
-        if ((c0 & 15u) == 4 && (int64_t)(c0 >> 4) == r->l_seq && (c1 & 15u) == 3) {
-            const uint8_t* t = r->qual + r->l_seq;
-            const uint8_t* const tend = p + block;
-            while (t + 3 <= tend) {
-                const char ty = (char)t[2];
-                const uint8_t* v = t + 3;
-                int64_t sz = -1;
-                if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
-                else if (ty == 's' || ty == 'S') sz = 2;
-                else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
-                else if (ty == 'Z' || ty == 'H') {
-                    const void* z = memchr(v, 0, (size_t)(tend - v));
-                    if (!z) return false;
-                    sz = (const uint8_t*)z - v + 1;
-                } else if (ty == 'B') {
-                    if (v + 5 > tend) return false;
-                    const char sub = (char)v[0];
-                    const int64_t cnt = rd_u32(v + 1);
-                    const int64_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
-                    sz = 5 + cnt * es;
-                    if (t[0] == 'C' && t[1] == 'G' && sub == 'I' && v + sz <= tend) {
-                        r->cigar = v + 5;
-                        r->n_cigar = (int32_t)cnt;
-                        break;
-                    }
-                }
-                if (sz < 0 || v + sz > tend) return false;
-                t = v + sz;
-            }
-        }
-    }
-    return true;
-}
 
 // Aligned (M, =, X) runs of one alignment: read position, reference position, length, index of the first pair.
 struct Runs {

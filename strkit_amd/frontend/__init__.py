@@ -11,10 +11,10 @@ from .fasta import Fasta, write_fasta
 from .bam import AlignedSegment, BamFile, read_bam, write_bam
 from .extract import (CigarIndex, LocusReadCoords, LowMeanBaseQual, find_pair_by_ref_pos, get_aligned_pairs,
                       get_read_coords_from_cigar, get_read_coords_from_matched_pairs, get_sequence_data_for_locus)
-from .native import IndexedBam, NativeBam, extract_reads
+from .native import DeviceBam, IndexedBam, NativeBam, extract_reads
 from .call import call_blocks, call_locus, call_sample, write_json
 
 __all__ = ["Locus", "LocusValidationError", "load_loci", "parse_last_column", "parse_loci_bed", "valid_motif",
            "validate_locus", "Fasta", "write_fasta", "AlignedSegment", "BamFile", "read_bam", "write_bam",
            "CigarIndex", "LocusReadCoords", "LowMeanBaseQual", "find_pair_by_ref_pos", "get_aligned_pairs", "get_read_coords_from_cigar",
-           "get_read_coords_from_matched_pairs", "get_sequence_data_for_locus", "call_sample", "call_locus", "call_blocks", "write_json", "NativeBam", "IndexedBam", "extract_reads"]
+           "get_read_coords_from_matched_pairs", "get_sequence_data_for_locus", "call_sample", "call_locus", "call_blocks", "write_json", "NativeBam", "IndexedBam", "DeviceBam", "extract_reads"]

@@ -26,7 +26,7 @@ from .extract import (LowMeanBaseQual, MIN_AVG_PHRED, get_read_coords_from_cigar
                       get_sequence_data_for_locus)
 from .fasta import Fasta
 from .loci import Locus, load_loci, parse_loci_bed, resolve_contig
-from .native import IndexedBam, NativeBam, extract_reads, realign_cigar_to_read_alignment
+from .native import DeviceBam, IndexedBam, NativeBam, extract_reads, realign_cigar_to_read_alignment
 from .output import read_weights
 
 __all__ = ["CallOptions", "call_sample", "call_locus", "call_blocks", "call_blocks_sharded", "deal_locus_blocks", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
@@ -228,11 +228,23 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
                 min_avg_phred: int = MIN_AVG_PHRED, max_reads: int = MAX_READS, respect_ref: bool = False,
                 sample_id: str | None = None, ctx: _lib.Context | None = None, processes: int = 1,
                 rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE,
-                tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL) -> dict:
-    if isinstance(bam, str):     # a path: block-wise access through the .bai index when there is one, else the whole stream
+                tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL, front_end: str = "auto") -> dict:
+    """`front_end` (for a `bam` given as a path): "device" = the file is inflated, scanned and cut on the GPU (DeviceBam: its
+    decompressed form, about six times the file, has to fit in device memory next to the workspace; no realignment), "host" =
+    block-wise through the .bai on the host cores (IndexedBam) or, without an index, the whole stream (NativeBam), "auto" =
+    "device" when `realign` is off and the file is below 24 GB, else "host"."""
+    t_open = time.perf_counter()
+    if isinstance(bam, str):
         import os
+        if front_end not in ("auto", "device", "host"):
+            raise ValueError("front_end must be auto, device or host")
         has_index = os.path.exists(bam + ".bai") or os.path.exists(os.path.splitext(bam)[0] + ".bai")
-        bam = IndexedBam(bam) if has_index else NativeBam(bam)
+        if front_end == "device" and realign:
+            raise ValueError("the device front end does not realign reads")
+        use_device = front_end == "device" or (front_end == "auto" and not realign and os.path.getsize(bam) < (24 << 30) and
+                                               not _distributed())
+        bam = DeviceBam(bam) if use_device else (IndexedBam(bam) if has_index else NativeBam(bam))
+    t_open = time.perf_counter() - t_open       # device reader: upload + inflation + record scan of the whole file
     ref = Fasta(ref) if isinstance(ref, str) else ref
     t0 = time.perf_counter()
     opts = CallOptions(flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params, min_read_align_score, tie_rule, end_flags)
@@ -254,6 +266,8 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
     else:
         results, n_depth, tm = run(blocks)
     errors = tm.pop("errors", [])
+    tm["open_s"] = t_open
+    tm["front_end"] = "device" if isinstance(bam, DeviceBam) else "host"
     # same top-level layout as the reference's report (strkit/call/output/json_report.py:37-60,127-154)
     return {"sample_id": sample_id,
             "caller": {"name": "strkit_amd", "version": _lib.load().strk_version().decode()},
@@ -267,7 +281,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
             "results": results,
             "errors": errors,
             "avg_read_depth": n_depth / max(1, sum(1 for r in results if "reads" in r)),
-            "runtime": time.perf_counter() - t0, "stage_times": {k: round(v, 4) for k, v in tm.items()}}
+            "runtime": time.perf_counter() - t0, "stage_times": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm.items()}}
 
 
 def deal_locus_blocks(blocks: list[list[Locus]], world: int) -> list[list[int]]:
@@ -399,7 +413,7 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = Non
     re-run locus by locus so that only the locus that fails is lost; `stage times["errors"]` lists them."""
     opts = opts or CallOptions()
     ctx = ctx or _lib.default_context()
-    native = isinstance(bam, (NativeBam, IndexedBam))
+    native = isinstance(bam, (NativeBam, IndexedBam, DeviceBam))
     run_block = _call_block_native if native else _call_block_python
     results: list[dict] = []
     n_depth = 0
@@ -659,6 +673,8 @@ def _call_block_native(block, bam, ref: Fasta, opts: CallOptions, ctx, tm, ref_d
         read_off=np.concatenate(([0], np.cumsum(n_ok_per_locus))).astype(np.int32),
         motifs=np.frombuffer(b"".join(motifs), np.uint8).copy(),
         motif_off=np.concatenate(([0], np.cumsum(mlen))).astype(np.int32))
+    if "d_seqs" in ex:
+        batch.d_seqs = ex["d_seqs"]          # extracted on the device: counted where they are
     tm["extract_s"] += time.perf_counter() - t_a
     t_a = time.perf_counter()
     res, flt = _count(batch, opts, ctx, tm)

@@ -14,7 +14,7 @@ from .. import _lib
 from .bam import AlignedSegment, real_cigar
 from .loci import resolve_contig
 
-__all__ = ["NativeBam", "IndexedBam", "extract_reads", "realign_cigar_to_read_alignment", "bgzf_read"]
+__all__ = ["NativeBam", "IndexedBam", "DeviceBam", "extract_reads", "realign_cigar_to_read_alignment", "bgzf_read"]
 
 _SEQ_LUT = np.frombuffer(b"=ACMGRSVTWYHKDBN", np.uint8)
 
@@ -333,6 +333,116 @@ class IndexedBam:
         return out
 
 
+class DeviceBam(_Records):
+    """The alignment file resident in HBM: the compressed bytes are uploaded once, inflated by the device (strk_dbam_inflate:
+    one GPU lane per BGZF block), the records are found by the device (strk_dbam_scan: one lane per entry of the .bai linear
+    index walks the record chain to the next entry) and only their per-record fields come back to the host, where the
+    interval queries of _Records run on them as for any other reader.  Read extraction (extract_reads) and read names go
+    through the device as well, and the extracted bases never leave it: strk_count_loci_dseqs counts them where they are.
+    What this reader cannot do is substitute CIGARs (realigned reads): call_sample uses it when `realign` is off."""
+
+    def __init__(self, path: str, index: str | None = None, device: int = 0):
+        self.path = path
+        L = _lib.load()
+        comp = np.memmap(path, np.uint8, "r")
+        h = C.c_void_p()
+        _lib.check(L.strk_dbam_open(int(device), C.byref(h)))
+        self._h = h
+        nxt = C.c_int64(0)
+        tot = L.strk_dbam_inflate(h, comp.ctypes.data, comp.size, 0, 1 << 46, C.byref(nxt))
+        if tot < 0:
+            self.close()
+            _lib.check(int(tot))
+        self.n_bytes = int(tot)
+        self.data = None
+        # header: text, contigs, offset of the first record
+        n_head = min(self.n_bytes, 1 << 20)
+        while True:
+            head = np.empty(n_head, np.uint8)
+            _lib.check(L.strk_dbam_download(h, 0, n_head, head.ctypes.data))
+            try:
+                self.header_text, self.contigs, first = _parse_header(head)
+                break
+            except (struct.error, IndexError, ValueError):
+                if n_head >= self.n_bytes or n_head > (1 << 28):
+                    self.close()
+                    raise ValueError(f"{path}: not a BAM file") from None
+                n_head = min(self.n_bytes, n_head * 4)
+        # entry points of the record scan: the first record and what the 16 kb linear index points at
+        index = index or (path + ".bai" if os.path.exists(path + ".bai") else os.path.splitext(path)[0] + ".bai")
+        starts = [np.array([first], np.int64)]
+        if os.path.exists(index):
+            lin = IndexedBam._read_bai(index, len(self.contigs))
+            voff = np.unique(np.concatenate([x[x != 0] for x in lin] or [np.zeros(0, np.uint64)]).astype(np.uint64))
+            if voff.size:
+                off = np.empty(voff.size, np.int64)
+                _lib.check(L.strk_dbam_voffsets(h, voff.ctypes.data, voff.size, off.ctypes.data))
+                starts.append(off[(off > first) & (off < self.n_bytes)])
+        starts = np.unique(np.concatenate(starts)).astype(np.int64)
+        cap = self.n_bytes // 4096 + 4096
+        while True:
+            self._set_arrays(cap)
+            self.l_name = np.zeros(cap, np.int32)
+            n = L.strk_dbam_scan(h, starts.ctypes.data, starts.size, cap, *self._scan_ptrs(), self.l_name.ctypes.data)
+            if n < 0:
+                self.close()
+                _lib.check(int(n))
+            if n <= cap:
+                break
+            cap = int(n)
+        self._trim(int(n))
+        self.l_name = self.l_name[:int(n)]
+        self._build_index()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            _lib.load().strk_dbam_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def region(self, contig: str, beg: int, end: int, threads: int = 0, slot: int | None = None):
+        """Every record is resident: a region is the reader itself."""
+        return self
+
+    def _download(self, off: int, n: int) -> np.ndarray:
+        buf = np.empty(int(n), np.uint8)
+        _lib.check(_lib.load().strk_dbam_download(self._h, int(off), int(n), buf.ctypes.data))
+        return buf
+
+    def name(self, i: int) -> str:
+        return self.names(np.array([i]))[0]
+
+    def names(self, idx: np.ndarray) -> list[str]:
+        idx = np.asarray(idx, np.int64)
+        n = int(idx.size)
+        if n == 0:
+            return []
+        off = np.concatenate(([0], np.cumsum(np.maximum(self.l_name[idx] - 1, 0)))).astype(np.int64)
+        rec_off = np.ascontiguousarray(self.rec_off[idx], np.int64)
+        buf = np.empty(max(int(off[-1]), 1), np.uint8)
+        _lib.check(_lib.load().strk_dbam_names(self._h, n, rec_off.ctypes.data, off.ctypes.data, buf.ctypes.data))
+        text = buf[:int(off[-1])].tobytes().decode()
+        o = off.tolist()
+        return [text[o[i]:o[i + 1]] for i in range(n)]
+
+    def segment(self, i: int) -> AlignedSegment:
+        """One record brought to the host (tests, a look at a read; the hot path never does this)."""
+        o = int(self.rec_off[i])
+        block, = struct.unpack("<i", self._download(o, 4).tobytes())
+        one = _Region()
+        one.contigs = self.contigs
+        one.data = self._download(o, 4 + block)
+        one._set_arrays(1)
+        for k in ("tid", "pos", "end", "flag", "l_seq", "clip_l", "clip_r"):
+            getattr(one, k)[0] = getattr(self, k)[i]
+        return one.segment(0)
+
+
 def realign_cigar_to_read_alignment(cigar: np.ndarray) -> np.ndarray:
     """CIGAR of strk_realign (reference window as "query", read as "ref", leading free read bases as one D run) turned
     into the read's alignment to the reference: I and D swap, the leading run becomes a soft clip."""
@@ -354,6 +464,17 @@ def extract_reads(bam: NativeBam, rec_idx: np.ndarray, coords: np.ndarray, flank
     coords = np.ascontiguousarray(coords, np.int64).reshape(n, 4)
     status, nfl, ntr, nfr = (np.zeros(n, np.int32) for _ in range(4))
     seq_off = np.zeros(n + 1, np.int64)
+    if isinstance(bam, DeviceBam):
+        if alt:
+            raise NotImplementedError("DeviceBam does not take substitute CIGARs (realigned reads): use IndexedBam / NativeBam")
+        name_len = np.zeros(max(n, 1), np.int32)
+        d_seqs = C.c_void_p()
+        _lib.check(_lib.load().strk_dbam_extract(bam._h, n, rec_off.ctypes.data, coords.ctypes.data, int(flank_size), int(min_avg_phred),
+                                                 int(wildcard_threshold), status.ctypes.data, nfl.ctypes.data, ntr.ctypes.data,
+                                                 nfr.ctypes.data, seq_off.ctypes.data, name_len.ctypes.data, C.byref(d_seqs)))
+        # the bases stay on the device: `seqs` is a stand-in of the right length for code that only asks for sizes
+        return {"status": status, "nfl": nfl, "ntr": ntr, "nfr": nfr, "seqs": np.zeros(1, np.uint8), "seq_off": seq_off,
+                "d_seqs": d_seqs.value}
     a_cig = a_off = a_start = None
     if alt:
         a_off = np.zeros(n + 1, np.int64)

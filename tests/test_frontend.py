@@ -541,3 +541,30 @@ def test_fasta_loader_handles_line_shapes(tmp_path):
         g.fetch("nope", 0, 1)
     with pytest.raises(IndexError):
         g.fetch("a", 7, 9)
+
+
+def test_one_pass_boundary_walk_equals_the_run_index(tmp_path):
+    """strk_bamrec.h::read_coords_linear (what a GPU lane runs: one pass over the CIGAR, no arrays) against
+    strk_frontend.h's Runs + read_coords on random alignments and boundaries, including boundaries inside insertions,
+    deletions, soft clips and outside the alignment."""
+    import ctypes as C
+    from strkit_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(33)
+    ops = np.array([0, 7, 8, 1, 2, 4, 3, 5], np.uint32)          # M = X I D S N H
+    n_span = 0
+    for case in range(4000):
+        n = int(rng.integers(1, 14))
+        op = ops[rng.choice(len(ops), size=n, p=[0.25, 0.25, 0.1, 0.12, 0.12, 0.06, 0.05, 0.05])]
+        ln = rng.integers(0 if case % 7 == 0 else 1, 40, size=n).astype(np.uint32)
+        cigar = np.ascontiguousarray((ln << 4) | op, np.uint32)
+        start = int(rng.integers(0, 500))
+        ref_len = int(ln[np.isin(op, [0, 2, 3, 7, 8])].sum())
+        c = np.sort(rng.integers(start - 10, start + ref_len + 12, size=4)).astype(np.int64)
+        a, b = np.zeros(4, np.int64), np.zeros(4, np.int64)
+        rc = L.strk_read_coords_both(cigar.ctypes.data, n, start, c.ctypes.data, a.ctypes.data, b.ctypes.data)
+        assert rc in (0, 3), (case, rc, cigar.tolist(), start, c.tolist())
+        if rc == 3:
+            n_span += 1
+            assert np.array_equal(a, b), (case, cigar.tolist(), start, c.tolist(), a.tolist(), b.tolist())
+    assert n_span > 300

@@ -198,7 +198,7 @@ def test_indexed_and_whole_file_access_give_the_same_report(gpu_ctx, tmp_path):
     from strkit_amd.frontend.synth_large import make_dataset_large
     t = make_dataset_large(str(tmp_path), n_loci=450, depth=9, read_len=3000, seed=9, spacing=9000, procs=4)
     a = call_sample(NativeBam(t["paths"]["bam"]), t["paths"]["ref"], t["paths"]["loci"])
-    b = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"])          # a path with a .bai: IndexedBam
+    b = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"], front_end="host")   # a path with a .bai: IndexedBam
     assert "load_s" in b["stage_times"] and "load_s" not in a["stage_times"]
     assert a["results"] == b["results"] and len(a["results"]) == 450
     truth = {(int(x), int(y)): int(z) for x, y, z in t["truth"]}
@@ -266,3 +266,49 @@ def test_device_inflater_equals_the_host_one(gpu_ctx, tmp_path):
         assert L.strk_dbam_inflate(h, bad.ctypes.data, bad.size, 0, 1 << 40, C.byref(nxt)) < 0 and b"BGZF" in L.strk_last_error()
     finally:
         L.strk_dbam_close(h)
+
+
+def test_device_front_end_gives_the_host_report(gpu_ctx, tmp_path):
+    """DeviceBam (inflate, record scan, read extraction and names on the GPU; the bases never leave it) against the host
+    readers: the same records, the same extracted triples, the same report; noisy reads with low-quality bases and
+    quality-gated reads included."""
+    from strkit_amd import _lib
+    from strkit_amd.frontend import DeviceBam, IndexedBam, NativeBam, extract_reads
+    from strkit_amd.frontend.synth_large import make_dataset_large
+    t = make_dataset_large(str(tmp_path), n_loci=260, depth=9, read_len=3000, seed=19, spacing=9000, procs=4)
+    nb, db = NativeBam(t["paths"]["bam"]), DeviceBam(t["paths"]["bam"])
+    try:
+        assert db.n_records == nb.n_records and db.references == nb.references
+        for k in ("rec_off", "tid", "pos", "end", "flag", "l_seq", "clip_l", "clip_r"):
+            assert np.array_equal(getattr(db, k), getattr(nb, k)), k
+        some = np.arange(0, nb.n_records, 37)
+        assert db.names(some) == nb.names(some)
+        a, b = db.segment(int(some[3])), nb.segment(int(some[3]))
+        assert (a.name, a.start, a.end, a.query_sequence) == (b.name, b.start, b.end, b.query_sequence) and np.array_equal(a.cigar, b.cigar)
+        # extraction: every locus of the first blocks, all overlapping records (spanning and not)
+        blocks = load_loci(t["paths"]["loci"], max_block_size=40)
+        for blk in blocks[:3]:
+            lfc = np.array([l.left_flank_coord for l in blk]); rfc = np.array([l.right_flank_coord for l in blk])
+            rec, n_per = nb.fetch_many("chr1", lfc, rfc, 250)
+            rec_d, n_per_d = db.fetch_many("chr1", lfc, rfc, 250)
+            assert np.array_equal(rec, rec_d) and np.array_equal(n_per, n_per_d)
+            owner = np.repeat(np.arange(len(blk)), n_per)
+            coords = np.stack((lfc, np.array([l.left_coord for l in blk]), np.array([l.right_coord for l in blk]), rfc), axis=1)[owner]
+            for phred in (13, 39):
+                eh = extract_reads(nb, rec, coords, 70, phred)
+                ed = extract_reads(db, rec, coords, 70, phred)
+                for k in ("status", "nfl", "ntr", "nfr", "seq_off"):
+                    assert np.array_equal(eh[k], ed[k]), (k, phred)
+                got = np.empty(max(int(ed["seq_off"][-1]), 1), np.uint8)
+                _lib.check(_lib.load().strk_dbam_download_seqs(db._h, int(ed["seq_off"][-1]), got.ctypes.data))
+                assert np.array_equal(got[:int(ed["seq_off"][-1])], eh["seqs"]) and ed["d_seqs"]
+                assert (eh["status"] == 0).sum() > 0
+        host = call_sample(IndexedBam(t["paths"]["bam"]), t["paths"]["ref"], t["paths"]["loci"])
+        dev = call_sample(db, t["paths"]["ref"], t["paths"]["loci"])
+        auto = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"])               # auto: the device front end
+        assert host["results"] == dev["results"] == auto["results"] and len(dev["results"]) == 260
+        assert "load_s" not in auto["stage_times"]
+        with pytest.raises(ValueError):
+            call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"], realign=True, front_end="device")
+    finally:
+        db.close()

@@ -40,7 +40,7 @@ t0 = time.perf_counter()
 if "--profile" in sys.argv:
     pr = cProfile.Profile()
     pr.enable()
-rep = call.call_sample(d + "/reads.bam", d + "/ref.fa", d + "/loci.bed")
+rep = call.call_sample(d + "/reads.bam", d + "/ref.fa", d + "/loci.bed", front_end="host")
 if "--profile" in sys.argv:
     pr.disable()
     pstats.Stats(pr).sort_stats("cumtime").print_stats(25)
