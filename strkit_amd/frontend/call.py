@@ -234,6 +234,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
     block-wise through the .bai on the host cores (IndexedBam) or, without an index, the whole stream (NativeBam), "auto" =
     "device" when `realign` is off and the file is below 24 GB, else "host"."""
     t_open = time.perf_counter()
+    own_reader = isinstance(bam, str)
     if isinstance(bam, str):
         import os
         if front_end not in ("auto", "device", "host"):
@@ -261,10 +262,14 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
     def run(bl):
         return call_blocks(bl, bam, ref, opts, ctx)
 
-    if _distributed():          # launched under torch.distributed (one rank per GPU): shard the blocks
-        results, n_depth, tm = call_blocks_sharded(blocks, run, ref, respect_ref)
-    else:
-        results, n_depth, tm = run(blocks)
+    try:
+        if _distributed():          # launched under torch.distributed (one rank per GPU): shard the blocks
+            results, n_depth, tm = call_blocks_sharded(blocks, run, ref, respect_ref)
+        else:
+            results, n_depth, tm = run(blocks)
+    finally:
+        if own_reader and isinstance(bam, DeviceBam):
+            bam.close()             # gigabytes of device memory: not left to the garbage collector
     errors = tm.pop("errors", [])
     tm["open_s"] = t_open
     tm["front_end"] = "device" if isinstance(bam, DeviceBam) else "host"
