@@ -282,11 +282,12 @@ int strk_dbam_voffsets(strk_dbam* d, const uint64_t* voff, int64_t n, int64_t* o
  * host arrays (capacity cap) are filled, in stream order, when it fits. */
 int64_t strk_dbam_scan(strk_dbam* d, const int64_t* starts, int64_t n_starts, int64_t cap, int64_t* rec_off, int32_t* tid,
                        int32_t* pos, int32_t* end, int32_t* flag, int32_t* l_seq, int32_t* clip_l, int32_t* clip_r, int32_t* l_name);
-/* strk_extract_reads on the device (no substitute CIGARs): the bases stay in HBM (*d_seqs, valid until the next call on the
- * object), status / lengths / seq_off and the name length of every item come back. */
-int strk_dbam_extract(strk_dbam* d, int32_t n_items, const int64_t* rec_off, const int64_t* coords, int32_t flank_size,
-                      int32_t min_avg_phred, int32_t wildcard_threshold, int32_t* status, int32_t* nfl, int32_t* ntr, int32_t* nfr,
-                      int64_t* seq_off, int32_t* name_len, void** d_seqs);
+/* strk_extract_reads on the device (same arguments, alt_* may be NULL): the bases stay in HBM (*d_seqs, valid until the next
+ * call on the object), status / lengths / seq_off and the name length of every item come back. */
+int strk_dbam_extract(strk_dbam* d, int32_t n_items, const int64_t* rec_off, const int64_t* coords, const uint32_t* alt_cigar,
+                      const int64_t* alt_cigar_off, const int64_t* alt_start, int32_t flank_size, int32_t min_avg_phred,
+                      int32_t wildcard_threshold, int32_t* status, int32_t* nfl, int32_t* ntr, int32_t* nfr, int64_t* seq_off,
+                      int32_t* name_len, void** d_seqs);
 /* read names of n records into out[0 .. out_off[n]); out_off = running sum of the name lengths (input) */
 int strk_dbam_names(strk_dbam* d, int64_t n, const int64_t* rec_off, const int64_t* out_off, uint8_t* out);
 /* strk_count_loci with the bases already on the device (d_seqs; batch->seqs is ignored), everything else on the host */

@@ -21,7 +21,7 @@ def main(argv=None) -> int:
     c.add_argument("--realign", action="store_true")
     c.add_argument("--front-end", choices=("auto", "device", "host"), default="auto",
                    help="where the alignment file is inflated, scanned and cut: on the GPU (needs about six times the file in device "
-                        "memory; no --realign) or on the host cores, block by block through the .bai; auto = device without --realign")
+                        "memory) or on the host cores, block by block through the .bai; auto = device for files below 24 GB")
     c.add_argument("--respect-ref", action="store_true")
     # same names as `strkit call` (strkit/entry.py:20-342); --seed is accepted for command-line compatibility (the
     # per-read path has no random component), --processes sizes the locus blocks as the reference does (loci.py:193)

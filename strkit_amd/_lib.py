@@ -137,7 +137,8 @@ def load(build: bool = True):
         L.strk_dbam_scan.restype = C.c_int64
         L.strk_dbam_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 9
         L.strk_dbam_extract.restype = C.c_int
-        L.strk_dbam_extract.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6 + [C.POINTER(C.c_void_p)]
+        L.strk_dbam_extract.argtypes = ([C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p] * 6
+                                        + [C.POINTER(C.c_void_p)])
         L.strk_dbam_names.restype = C.c_int
         L.strk_dbam_names.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.strk_count_loci_dseqs.restype = C.c_int

@@ -230,9 +230,9 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
                 rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE,
                 tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL, front_end: str = "auto") -> dict:
     """`front_end` (for a `bam` given as a path): "device" = the file is inflated, scanned and cut on the GPU (DeviceBam: its
-    decompressed form, about six times the file, has to fit in device memory next to the workspace; no realignment), "host" =
-    block-wise through the .bai on the host cores (IndexedBam) or, without an index, the whole stream (NativeBam), "auto" =
-    "device" when `realign` is off and the file is below 24 GB, else "host"."""
+    decompressed form, about six times the file, has to fit in device memory next to the workspace), "host" = block-wise
+    through the .bai on the host cores (IndexedBam) or, without an index, the whole stream (NativeBam), "auto" = "device"
+    for a file below 24 GB in a single-process run, else "host"."""
     t_open = time.perf_counter()
     own_reader = isinstance(bam, str)
     if isinstance(bam, str):
@@ -240,10 +240,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
         if front_end not in ("auto", "device", "host"):
             raise ValueError("front_end must be auto, device or host")
         has_index = os.path.exists(bam + ".bai") or os.path.exists(os.path.splitext(bam)[0] + ".bai")
-        if front_end == "device" and realign:
-            raise ValueError("the device front end does not realign reads")
-        use_device = front_end == "device" or (front_end == "auto" and not realign and os.path.getsize(bam) < (24 << 30) and
-                                               not _distributed())
+        use_device = front_end == "device" or (front_end == "auto" and os.path.getsize(bam) < (24 << 30) and not _distributed())
         bam = DeviceBam(bam) if use_device else (IndexedBam(bam) if has_index else NativeBam(bam))
     t_open = time.perf_counter() - t_open       # device reader: upload + inflation + record scan of the whole file
     ref = Fasta(ref) if isinstance(ref, str) else ref

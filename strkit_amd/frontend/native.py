@@ -339,7 +339,7 @@ class DeviceBam(_Records):
     index walks the record chain to the next entry) and only their per-record fields come back to the host, where the
     interval queries of _Records run on them as for any other reader.  Read extraction (extract_reads) and read names go
     through the device as well, and the extracted bases never leave it: strk_count_loci_dseqs counts them where they are.
-    What this reader cannot do is substitute CIGARs (realigned reads): call_sample uses it when `realign` is off."""
+    A record comes to the host only when somebody asks for it as a segment (soft-clipped reads on their way to realignment)."""
 
     def __init__(self, path: str, index: str | None = None, device: int = 0):
         self.path = path
@@ -464,17 +464,6 @@ def extract_reads(bam: NativeBam, rec_idx: np.ndarray, coords: np.ndarray, flank
     coords = np.ascontiguousarray(coords, np.int64).reshape(n, 4)
     status, nfl, ntr, nfr = (np.zeros(n, np.int32) for _ in range(4))
     seq_off = np.zeros(n + 1, np.int64)
-    if isinstance(bam, DeviceBam):
-        if alt:
-            raise NotImplementedError("DeviceBam does not take substitute CIGARs (realigned reads): use IndexedBam / NativeBam")
-        name_len = np.zeros(max(n, 1), np.int32)
-        d_seqs = C.c_void_p()
-        _lib.check(_lib.load().strk_dbam_extract(bam._h, n, rec_off.ctypes.data, coords.ctypes.data, int(flank_size), int(min_avg_phred),
-                                                 int(wildcard_threshold), status.ctypes.data, nfl.ctypes.data, ntr.ctypes.data,
-                                                 nfr.ctypes.data, seq_off.ctypes.data, name_len.ctypes.data, C.byref(d_seqs)))
-        # the bases stay on the device: `seqs` is a stand-in of the right length for code that only asks for sizes
-        return {"status": status, "nfl": nfl, "ntr": ntr, "nfr": nfr, "seqs": np.zeros(1, np.uint8), "seq_off": seq_off,
-                "d_seqs": d_seqs.value}
     a_cig = a_off = a_start = None
     if alt:
         a_off = np.zeros(n + 1, np.int64)
@@ -488,6 +477,19 @@ def extract_reads(bam: NativeBam, rec_idx: np.ndarray, coords: np.ndarray, flank
             else:
                 a_off[i + 1] = a_off[i]
         a_cig = np.concatenate(parts) if parts else np.zeros(1, np.uint32)
+    if isinstance(bam, DeviceBam):
+        name_len = np.zeros(max(n, 1), np.int32)
+        d_seqs = C.c_void_p()
+        _lib.check(_lib.load().strk_dbam_extract(bam._h, n, rec_off.ctypes.data, coords.ctypes.data,
+                                                 a_cig.ctypes.data if a_cig is not None else None,
+                                                 a_off.ctypes.data if a_off is not None else None,
+                                                 a_start.ctypes.data if a_start is not None else None,
+                                                 int(flank_size), int(min_avg_phred), int(wildcard_threshold), status.ctypes.data,
+                                                 nfl.ctypes.data, ntr.ctypes.data, nfr.ctypes.data, seq_off.ctypes.data,
+                                                 name_len.ctypes.data, C.byref(d_seqs)))
+        # the bases stay on the device: `seqs` is a stand-in for code that only asks for sizes
+        return {"status": status, "nfl": nfl, "ntr": ntr, "nfr": nfr, "seqs": np.zeros(1, np.uint8), "seq_off": seq_off,
+                "d_seqs": d_seqs.value}
     L = _lib.load()
 
     def call(seqs_ptr, cap):

@@ -73,6 +73,9 @@ def test_soft_clipped_expansions_come_back_with_realign(gpu_ctx, tmp_path):
             recovered += bool(rd.get("realn"))
         assert set(b["reads"]) == set(truth["reads"])
     assert lost > 10 and recovered >= lost
+    # the device front end (the default) and the host one realign the same reads to the same answers
+    assert realn["stage_times"]["front_end"] == "device"
+    assert call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"], realign=True, front_end="host")["results"] == realn["results"]
 
 
 def test_cli_writes_json(gpu_ctx, tmp_path):
@@ -309,6 +312,6 @@ def test_device_front_end_gives_the_host_report(gpu_ctx, tmp_path):
         assert host["results"] == dev["results"] == auto["results"] and len(dev["results"]) == 260
         assert "load_s" not in auto["stage_times"]
         with pytest.raises(ValueError):
-            call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"], realign=True, front_end="device")
+            call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"], front_end="gpu")
     finally:
         db.close()
