@@ -152,6 +152,9 @@ def run_e2e(data: dict) -> dict:
         return {"loci": len(rep["results"]), "reads": n_reads, "wall_s": wall, "loci_per_s": len(rep["results"]) / wall,
                 "reads_per_s": n_reads / wall, "calling_s": calling, "stage_s": st,
                 "device_share_of_calling": (st.get("count_device_s", 0.0)) / max(calling, 1e-9),
+                # device front end: kernels (inflation, scan, extraction, counting) over opening the file + calling
+                "device_share_of_open_and_calling": ((st.get("count_device_s", 0.0) + st.get("front_end_device_s", 0.0))
+                                                     / max(calling + st.get("open_s", 0.0), 1e-9)) if "front_end_device_s" in st else None,
                 "reads_with_true_allele_cn": n_true}, rep["results"]
 
     dev, rows_dev = one("device")

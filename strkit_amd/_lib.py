@@ -49,7 +49,7 @@ EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk
            "strk_score_ref_table", "strk_ref_repeat_count", "strk_ref_repeat_count_batch", "strk_realign", "strk_bam_scan",
            "strk_extract_reads", "strk_bgzf_inflate", "strk_bgzf_inflate_range", "strk_bam_names", "strk_bam_scan_piece",
            "strk_dbam_open", "strk_dbam_close", "strk_dbam_inflate", "strk_dbam_download", "strk_dbam_data", "strk_bgzf_inflate_sw",
-           "strk_dbam_download_seqs", "strk_dbam_voffsets", "strk_dbam_scan", "strk_dbam_extract", "strk_dbam_names", "strk_count_loci_dseqs", "strk_read_coords_both")
+           "strk_dbam_download_seqs", "strk_dbam_kernel_ms", "strk_dbam_voffsets", "strk_dbam_scan", "strk_dbam_extract", "strk_dbam_names", "strk_count_loci_dseqs", "strk_read_coords_both")
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -132,6 +132,8 @@ def load(build: bool = True):
         L.strk_dbam_data.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.strk_dbam_download_seqs.restype = C.c_int
         L.strk_dbam_download_seqs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.strk_dbam_kernel_ms.restype = C.c_double
+        L.strk_dbam_kernel_ms.argtypes = [C.c_void_p]
         L.strk_dbam_voffsets.restype = C.c_int
         L.strk_dbam_voffsets.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.strk_dbam_scan.restype = C.c_int64

@@ -265,11 +265,14 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
         else:
             results, n_depth, tm = run(blocks)
     finally:
+        fe_kernel_s = bam.kernel_s() if isinstance(bam, DeviceBam) else None
         if own_reader and isinstance(bam, DeviceBam):
             bam.close()             # gigabytes of device memory: not left to the garbage collector
     errors = tm.pop("errors", [])
     tm["open_s"] = t_open
     tm["front_end"] = "device" if isinstance(bam, DeviceBam) else "host"
+    if fe_kernel_s is not None:
+        tm["front_end_device_s"] = fe_kernel_s      # inflation + record scan + extraction kernels (HIP events)
     # same top-level layout as the reference's report (strkit/call/output/json_report.py:37-60,127-154)
     return {"sample_id": sample_id,
             "caller": {"name": "strkit_amd", "version": _lib.load().strk_version().decode()},

@@ -394,6 +394,10 @@ class DeviceBam(_Records):
         self.l_name = self.l_name[:int(n)]
         self._build_index()
 
+    def kernel_s(self) -> float:
+        """HIP-event time of all the kernels this reader has launched (inflation, record scan, extraction), in seconds."""
+        return float(_lib.load().strk_dbam_kernel_ms(self._h)) / 1e3 if getattr(self, "_h", None) is not None else 0.0
+
     def close(self):
         if getattr(self, "_h", None) is not None:
             _lib.load().strk_dbam_close(self._h)
