@@ -269,6 +269,11 @@ void strk_dbam_close(strk_dbam* d);
  * max_out bytes, into the object's device buffer (one GPU lane per block, CRC checked); *next_coff = offset of the first block
  * not taken.  Returns the decompressed bytes or a negative STRK_E_* code. */
 int64_t strk_dbam_inflate(strk_dbam* d, const uint8_t* comp, int64_t n_comp, int64_t coff, int64_t max_out, int64_t* next_coff);
+/* The same for a whole file read by the library: `threads` readers (0: default) pread pieces of it into a ring of pinned
+ * buffers, each piece is copied to the device as it comes in, the block headers are walked meanwhile and all blocks are
+ * inflated by one launch at the end.  *n_comp (may be NULL) = size of the file.  Returns the decompressed bytes or a negative
+ * STRK_E_* code. */
+int64_t strk_dbam_inflate_file(strk_dbam* d, const char* path, int threads, int64_t* n_comp);
 /* bytes [off, off + n) of the decompressed stream -> host (headers, a single record for realignment, tests) */
 int strk_dbam_download(strk_dbam* d, int64_t off, int64_t n, uint8_t* out);
 /* the first n bytes of the bases of the last strk_dbam_extract -> host (tests) */

@@ -17,13 +17,18 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+#include <fcntl.h>
 #include <sched.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "../../include/strkit_amd.h"

@@ -7,10 +7,14 @@
 //
 // Decoder, per stream (one lane):
 //   * canonical Huffman decoding WITHOUT a per-bit loop and WITHOUT a big look-up table: the next 15 stream bits are
-//     bit-reversed into a left-justified value v; the code length is 1 + the number of per-length limits v has reached
-//     (limit[L] = left-justified end of the codes of length L; fifteen compares against registers, branch-free), the symbol
-//     is sym[base[L] + (v >> (15 - L))].  Per-lane state: 2 x 15 limits in registers, the sorted symbol arrays and the two
-//     base arrays in a 768-byte slot of LDS (strk_inf::Tables).
+//     bit-reversed into a left-justified value v; the code length L is 1 + the number of per-length limits v has reached
+//     (limit[L] = left-justified end of the codes of length L; fifteen compare-and-select steps against registers,
+//     branch-free: each step that holds replaces a word that carries L, the base and the split of that length), the symbol
+//     is sym[base[L] + (v >> (15 - L))].  Per-lane state: 2 x (15 limits + 16 words) in registers, the sorted symbol arrays
+//     in a 320-byte slot of LDS (strk_inf::Tables) — one LDS read per symbol.  A lane's time per block does not depend on
+//     how many other lanes run (it waits: for LDS, for its own stores), so the kernel's rate is the number of resident
+//     lanes, which LDS sets: the symbols are kept as bytes; the ninth bit of a literal/length symbol is not stored, it
+//     follows from the position (the symbols of one length are sorted, the literals come first: one split index per length).
 //   * a 64-bit bit buffer refilled when fewer than 48 bits are left, from eight bytes that were loaded when the previous
 //     refill moved the read position (the caller pads the input by 16 bytes): a refill never waits for memory;
 //   * literals are collected in a register and stored eight at a time (a lane's loads wait for its older stores: the memory
@@ -22,6 +26,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <utility>
 
 #if defined(__HIPCC__)
 #define STRK_INF_HD __host__ __device__ inline
@@ -43,16 +48,17 @@ namespace strk_inf {
 constexpr int kErrNone = 0, kErrBadBlockType = 1, kErrBadCode = 2, kErrBadLengths = 3, kErrOverrun = 4, kErrBadDistance = 5,
               kErrStored = 6, kErrSize = 7, kErrCrc = 8;
 
-struct Tables {           // 704 bytes per stream: LDS on the device
-    uint16_t lsym[288];   // literal/length symbols sorted by (code length, symbol)
-    uint16_t dsym[32];    // distance symbols, likewise
-    int16_t lbase[16];    // per length L: index of the first symbol of that length - first code of that length
-    int16_t dbase[16];
+struct Tables {           // 320 bytes per stream: LDS on the device
+    uint8_t lsym[288];    // literal/length symbols sorted by (code length, symbol), low eight bits
+    uint8_t dsym[32];     // distance symbols, likewise (whole); the code-length code's while a block header is read
 };
 constexpr int kLensBytes = 19 + 286 + 30 + 1;   // code lengths while a block header is being read (global scratch on the device)
 
-struct Limits {
-    uint32_t v[15];       // limit[L - 1], L = 1..15: left-justified (15-bit) end of the codes of length L
+struct Code {             // one canonical code: registers on the device (every index is a constant after unrolling)
+    uint32_t lim[15];     // lim[L - 1], L = 1..15: left-justified (15-bit) end of the codes of length L
+    uint32_t word[16];    // word[L - 1]: bits 0-15 = (int16) index of the first symbol of length L - first code of length L,
+                          // bits 16-24 = index of the first symbol >= 256 of that length (the split), bits 28-31 = L;
+                          // word[15] = 0: no code starts like that
 };
 
 STRK_INF_HD uint32_t bitrev15(uint32_t x) {   // the low 15 bits of x, reversed
@@ -69,46 +75,60 @@ STRK_INF_HD uint32_t bitrev15(uint32_t x) {   // the low 15 bits of x, reversed
 
 // Canonical code from `n` code lengths: sorted symbols, bases and limits.  false: over-subscribed or (when more than one
 // code is used) incomplete set of lengths.
-STRK_INF_HD bool build(const uint8_t* lens, int n, uint16_t* sym, int16_t* base, Limits* lim) {
-    int count[16];
+template <class F, int... K>
+STRK_INF_HD void for_each_length_impl(F&& f, std::integer_sequence<int, K...>) { (f(std::integral_constant<int, K>()), ...); }
+template <class F>
+STRK_INF_HD void for_each_length(F&& f) { for_each_length_impl(f, std::make_integer_sequence<int, 15>()); }   // f(0) ... f(14)
+
+STRK_INF_HD bool build(const uint8_t* lens, int n, uint8_t* sym, Code* c) {
+    int count[16];   // low half: symbols of that length; high half: those below 256 among them
     STRK_INF_LOOP
     for (int l = 0; l < 16; ++l) count[l] = 0;
     STRK_INF_LOOP
-    for (int i = 0; i < n; ++i) ++count[lens[i] & 15];
+    for (int i = 0; i < n; ++i) count[lens[i] & 15] += i < 256 ? 0x10001 : 1;
     int offs[16];
     int code = 0, used = 0, left = 1;
     offs[1] = 0;
-    STRK_INF_LOOP
-    for (int l = 1; l <= 15; ++l) {
+    bool over = false;
+    // one step per length, written out at compile time: every index into `c` is a constant from the start, so the code
+    // never exists in memory (a loop that is unrolled later leaves the compiler time to turn the select chain of code_word
+    // into one load from a selected address of a scratch copy)
+    for_each_length([&](auto lc) {
+        constexpr int l = decltype(lc)::value + 1;
+        const int cnt = count[l] & 0xffff, lits = count[l] >> 16;
         left <<= 1;
-        left -= count[l];
-        if (left < 0) return false;                      // over-subscribed
+        left -= cnt;
+        over |= left < 0;                                // over-subscribed
         code <<= 1;                                      // first code of length l
-        base[l] = (int16_t)(offs[l] - code);
-        code += count[l];
-        lim->v[l - 1] = (uint32_t)code << (15 - l);
-        used += count[l];
-        if (l < 15) offs[l + 1] = offs[l] + count[l];
-    }
-    base[0] = 0;
+        c->word[l - 1] = (uint32_t)(uint16_t)(int16_t)(offs[l] - code) | ((uint32_t)(offs[l] + lits) << 16) | ((uint32_t)l << 28);
+        code += cnt;
+        c->lim[l - 1] = (uint32_t)code << (15 - l);
+        used += cnt;
+        if (l < 15) offs[l + 1] = offs[l] + cnt;
+    });
+    c->word[15] = 0;
+    if (over) return false;
     if (left > 0 && used > 1) return false;              // incomplete (a single code of length 1 is allowed: RFC 1951 3.2.7)
     STRK_INF_LOOP
     for (int i = 0; i < n; ++i) {
         const int l = lens[i] & 15;
-        if (l) sym[offs[l]++] = (uint16_t)i;
+        if (l) sym[offs[l]++] = (uint8_t)i;
     }
     return true;
 }
 
-// length of the code that the left-justified 15-bit value v starts with (16: no code)
-STRK_INF_HD int code_len(uint32_t v, const Limits& lim) {
-    int len = 1;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int k = 0; k < 15; ++k) len += v >= lim.v[k] ? 1 : 0;
-    return len;
+// the word of the code that the left-justified 15-bit value v starts with (0: no code).  The limits do not decrease with
+// the length, so the last step that holds is the one of the code's own length.
+STRK_INF_HD uint32_t code_word(uint32_t v, const Code& c) {
+    uint32_t w = c.word[0];
+    for_each_length([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        w = v >= c.lim[k] ? c.word[k + 1] : w;
+    });
+    return w;
 }
+// index of the symbol in the sorted array, given the word
+STRK_INF_HD int code_at(uint32_t v, uint32_t w) { return (int)(int16_t)(w & 0xffffu) + (int)(v >> (15 - (int)(w >> 28))); }
 
 struct Stream {
     const uint8_t* p;     // next input byte to load
@@ -133,7 +153,7 @@ STRK_INF_HD uint32_t take(Stream& s, int n) {   // n <= 32 bits, LSB first
 }
 
 // Reads a dynamic block header (HLIT, HDIST, HCLEN, the code-length code, the two sets of lengths) and builds the tables.
-STRK_INF_HD int read_dynamic(Stream& s, Tables* t, uint8_t* lens, Limits* ll, Limits* dl) {
+STRK_INF_HD int read_dynamic(Stream& s, Tables* t, uint8_t* lens, Code* ll, Code* dl) {
     refill(s);
     const int nlen = (int)take(s, 5) + 257, ndist = (int)take(s, 5) + 1, ncode = (int)take(s, 4) + 4;
     if (nlen > 286 || ndist > 30) return kErrBadLengths;
@@ -145,17 +165,19 @@ STRK_INF_HD int read_dynamic(Stream& s, Tables* t, uint8_t* lens, Limits* ll, Li
         if (s.cnt < 3) refill(s);
         lens[order[i]] = (uint8_t)take(s, 3);
     }
-    Limits cl;
-    // the code-length code's symbols and bases live in the distance slots until the real distance code is built
-    if (!build(lens, 19, t->dsym, t->dbase, &cl)) return kErrBadLengths;
+    // the code-length code: its words in the distance code's registers, its symbols in the distance slots, until the real
+    // distance code is built
+    Code& cl = *dl;
+    if (!build(lens, 19, t->dsym, &cl)) return kErrBadLengths;
     int i = 0;
     STRK_INF_LOOP
     while (i < nlen + ndist) {
         refill(s);
         const uint32_t v = bitrev15((uint32_t)s.buf);
-        const int len = code_len(v, cl);
-        if (len > 7) return kErrBadCode;
-        const int sym = t->dsym[t->dbase[len] + (int)(v >> (15 - len))];
+        const uint32_t w = code_word(v, cl);
+        const int len = (int)(w >> 28);
+        if (len == 0 || len > 7) return kErrBadCode;
+        const int sym = t->dsym[code_at(v, w)];
         s.buf >>= len; s.cnt -= len;
         if (sym < 16) { lens[19 + i++] = (uint8_t)sym; continue; }
         int prev = 0, rep;
@@ -170,12 +192,12 @@ STRK_INF_HD int read_dynamic(Stream& s, Tables* t, uint8_t* lens, Limits* ll, Li
         while (rep--) lens[19 + i++] = (uint8_t)prev;
     }
     if (lens[19 + 256] == 0) return kErrBadLengths;   // no end-of-block code
-    if (!build(lens + 19, nlen, t->lsym, t->lbase, ll)) return kErrBadLengths;
-    if (!build(lens + 19 + nlen, ndist, t->dsym, t->dbase, dl)) return kErrBadLengths;
+    if (!build(lens + 19, nlen, t->lsym, ll)) return kErrBadLengths;
+    if (!build(lens + 19 + nlen, ndist, t->dsym, dl)) return kErrBadLengths;
     return kErrNone;
 }
 
-STRK_INF_HD int set_fixed(Tables* t, uint8_t* lens, Limits* ll, Limits* dl) {
+STRK_INF_HD int set_fixed(Tables* t, uint8_t* lens, Code* ll, Code* dl) {
     STRK_INF_LOOP
     for (int i = 0; i < 144; ++i) lens[i] = 8;
     STRK_INF_LOOP
@@ -184,13 +206,13 @@ STRK_INF_HD int set_fixed(Tables* t, uint8_t* lens, Limits* ll, Limits* dl) {
     for (int i = 256; i < 280; ++i) lens[i] = 7;
     STRK_INF_LOOP
     for (int i = 280; i < 288; ++i) lens[i] = 8;
-    if (!build(lens, 288, t->lsym, t->lbase, ll)) return kErrBadLengths;
+    if (!build(lens, 288, t->lsym, ll)) return kErrBadLengths;
     STRK_INF_LOOP
     for (int i = 0; i < 30; ++i) lens[i] = 5;
     // (the fixed distance code uses 30 of its 32 five-bit codes: build() would call it incomplete)
     STRK_INF_LOOP
     for (int i = 30; i < 32; ++i) lens[i] = 5;
-    if (!build(lens, 32, t->dsym, t->dbase, dl)) return kErrBadLengths;
+    if (!build(lens, 32, t->dsym, dl)) return kErrBadLengths;
     return kErrNone;
 }
 
@@ -205,7 +227,7 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
     Stream s;
     s.p = in; s.end = in + in_len; s.buf = 0; s.cnt = 0;
     load_ahead(s);
-    Limits ll, dl;
+    Code ll, dl;
     int pos = 0;          // bytes written to `out`
     uint64_t ob = 0;      // literals not yet written: `on` bytes (out[pos .. pos + on)), stored eight at a time
     int on = 0;
@@ -291,16 +313,18 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
             continue;
         }
         int sym, len;
-        uint32_t v;
+        uint32_t v, w;
         for (;;) {
             if (s.cnt < 48) {
                 refill(s);
                 if (s.p - 8 > s.end) return kErrOverrun;     // the stream ran past its payload
             }
             v = bitrev15((uint32_t)s.buf);
-            len = code_len(v, ll);
-            if (len > 15) return kErrBadCode;
-            sym = t->lsym[t->lbase[len] + (int)(v >> (15 - len))];
+            w = code_word(v, ll);
+            len = (int)(w >> 28);
+            if (len == 0) return kErrBadCode;
+            const int at = code_at(v, w);
+            sym = t->lsym[at] | (at >= (int)((w >> 16) & 0x1ffu) ? 256 : 0);
             s.buf >>= len; s.cnt -= len;
             if (sym >= 256) break;
             if (pos + on >= out_len) return kErrSize;
@@ -315,9 +339,10 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
         if (sym > 285) return kErrBadCode;
         const int mlen = lbase_tab[sym - 257] + (int)take(s, lext_tab[sym - 257]);
         v = bitrev15((uint32_t)s.buf);
-        len = code_len(v, dl);
-        if (len > 15) return kErrBadCode;
-        const int dsymv = t->dsym[t->dbase[len] + (int)(v >> (15 - len))];
+        w = code_word(v, dl);
+        len = (int)(w >> 28);
+        if (len == 0) return kErrBadCode;
+        const int dsymv = t->dsym[code_at(v, w)];
         s.buf >>= len; s.cnt -= len;
         if (dsymv > 29) return kErrBadCode;
         const int dist = dbase_tab[dsymv] + (int)take(s, dext_tab[dsymv]);

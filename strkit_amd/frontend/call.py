@@ -127,6 +127,7 @@ def _loci_with_ref_data_packed(block: list[Locus], ref: Fasta, respect_ref: bool
     lens = (end - 1 - lfc)[idx]
     seq_off = np.concatenate(([0], np.cumsum(lens)))
     seqs = np.empty(int(seq_off[-1]), np.uint8)
+    last_base = np.empty(idx.size, np.uint8)                     # the base after each window (ref_total_seq has it)
     by_contig: dict[str, list[int]] = {}
     for k, i in enumerate(idx.tolist()):
         by_contig.setdefault(contig_of[i], []).append(k)
@@ -137,6 +138,7 @@ def _loci_with_ref_data_packed(block: list[Locus], ref: Fasta, respect_ref: bool
         owner = np.repeat(np.arange(len(ks)), ln)
         within = np.arange(int(ln.sum())) - (np.cumsum(ln) - ln)[owner]
         seqs[seq_off[ks][owner] + within] = arrays[c][src0[owner] + within]
+        last_base[ks] = arrays[c][end[idx[ks]] - 1]
     nfl_i, ntr_i, nfr_i = nfl[idx], (rc - lc)[idx], nfr[idx]
     # "reference has flanking N[...] sequence" (call_locus.py:786-787): only loci with an N next to the tract are looked at
     n_code = (ord("N"), ord("n"))
@@ -166,15 +168,14 @@ def _loci_with_ref_data_packed(block: list[Locus], ref: Fasta, respect_ref: bool
     text = seqs.tobytes().decode("ascii")
     so = seq_off.tolist()
     o9l = o9.tolist()
+    last_chr = [chr(x) for x in last_base.tolist()]
     for k, i in enumerate(idx.tolist()):
         locus = block[i]
         cn, _sc, l_off, r_off, _n1, _n2, a, b, _c = o9l[k]
         base = so[k]
         total_end = so[k + 1]
-        arr = arrays[contig_of[i]]
-        e = int(end[i])
         # the reference's ref_total_seq carries one more base (call_locus.py:770-772)
-        out[i] = {"ref_cn": cn, "ref_total_seq": text[base:total_end] + chr(arr[e - 1]),
+        out[i] = {"ref_cn": cn, "ref_total_seq": text[base:total_end] + last_chr[k],
                   "ref_seq": text[base + a:base + a + b], "ref_left_flank_seq": text[base:base + a],
                   "ref_right_flank_seq": text[base + a + b:total_end],
                   "left_coord_adj": locus.left_coord if respect_ref else locus.left_coord - max(0, l_off),
@@ -273,6 +274,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
     tm["front_end"] = "device" if isinstance(bam, DeviceBam) else "host"
     if fe_kernel_s is not None:
         tm["front_end_device_s"] = fe_kernel_s      # inflation + record scan + extraction kernels (HIP events)
+        tm["open_stage_s"] = dict(getattr(bam, "open_stage_s", {}))
     # same top-level layout as the reference's report (strkit/call/output/json_report.py:37-60,127-154)
     return {"sample_id": sample_id,
             "caller": {"name": "strkit_amd", "version": _lib.load().strk_version().decode()},

@@ -7,6 +7,7 @@ import ctypes as C
 import gzip
 import os
 import struct
+import time
 
 import numpy as np
 
@@ -344,12 +345,13 @@ class DeviceBam(_Records):
     def __init__(self, path: str, index: str | None = None, device: int = 0):
         self.path = path
         L = _lib.load()
-        comp = np.memmap(path, np.uint8, "r")
         h = C.c_void_p()
         _lib.check(L.strk_dbam_open(int(device), C.byref(h)))
         self._h = h
-        nxt = C.c_int64(0)
-        tot = L.strk_dbam_inflate(h, comp.ctypes.data, comp.size, 0, 1 << 46, C.byref(nxt))
+        tm = self.open_stage_s = {}
+        t0 = time.perf_counter()
+        tot = L.strk_dbam_inflate_file(h, os.fsencode(path), 0, None)
+        tm["upload_inflate_s"] = round(time.perf_counter() - t0, 4)
         if tot < 0:
             self.close()
             _lib.check(int(tot))
@@ -379,6 +381,8 @@ class DeviceBam(_Records):
                 _lib.check(L.strk_dbam_voffsets(h, voff.ctypes.data, voff.size, off.ctypes.data))
                 starts.append(off[(off > first) & (off < self.n_bytes)])
         starts = np.unique(np.concatenate(starts)).astype(np.int64)
+        tm["header_index_s"] = round(time.perf_counter() - t0 - tm["upload_inflate_s"], 4)
+        t1 = time.perf_counter()
         cap = self.n_bytes // 4096 + 4096
         while True:
             self._set_arrays(cap)
@@ -390,9 +394,12 @@ class DeviceBam(_Records):
             if n <= cap:
                 break
             cap = int(n)
+        tm["scan_s"] = round(time.perf_counter() - t1, 4)
+        t1 = time.perf_counter()
         self._trim(int(n))
         self.l_name = self.l_name[:int(n)]
         self._build_index()
+        tm["record_index_s"] = round(time.perf_counter() - t1, 4)
 
     def kernel_s(self) -> float:
         """HIP-event time of all the kernels this reader has launched (inflation, record scan, extraction), in seconds."""

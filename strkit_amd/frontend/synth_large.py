@@ -180,7 +180,7 @@ def make_dataset_large(out_dir: str, n_loci: int = 10000, depth: int = 30, read_
                        motif_len: tuple[int, int] = (3, 6), cn_range: tuple[int, int] = (8, 40), sub: float = 0.001,
                        indel: float = 0.002, low_qual: float = 0.0005, flank_size: int = 70, spacing: int | None = None,
                        procs: int | None = None) -> dict:
-    """Writes ref.fa, loci.bed, reads.bam and reads.bam.bai under out_dir.  Returns the paths and the truth as arrays:
+    """Writes ref.fa (+ .fai), loci.bed, reads.bam and reads.bam.bai under out_dir.  Returns the paths and the truth as arrays:
     `truth[:, 0]` locus, `[:, 1]` read number (name l<locus>_r<read>), `[:, 2]` the copy number of the read's allele."""
     import multiprocessing as mp
     rng = np.random.default_rng(seed)
@@ -222,6 +222,8 @@ def make_dataset_large(out_dir: str, n_loci: int = 10000, depth: int = 30, read_
         fh.write(lines.tobytes())
         if rem:
             fh.write(np.asarray(genome[full * 60:]).tobytes() + b"\n")
+    with open(os.path.join(out_dir, "ref.fa.fai"), "w") as fh:      # what `samtools faidx` writes (the reference needs it too)
+        fh.write(f"chr1\t{glen}\t6\t60\t61\n")
     with open(os.path.join(out_dir, "loci.bed"), "w") as fh:
         for i, (s, e, m, _) in enumerate(loci):
             fh.write(f"chr1\t{s}\t{e}\t" + (m if i % 2 else f"ID=syn{i};MOTIF={m}") + "\n")

@@ -541,6 +541,31 @@ def test_fasta_loader_handles_line_shapes(tmp_path):
         g.fetch("nope", 0, 1)
     with pytest.raises(IndexError):
         g.fetch("a", 7, 9)
+    # lines of one width are addressed in place (no stripped copy), LF and CR LF alike, with or without a .fai
+    from strkit_amd.frontend.fasta import _Contig
+    assert isinstance(f.array("chr1"), _Contig) and isinstance(g.array("c"), _Contig) and not isinstance(g.array("a"), _Contig)
+    crlf = str(tmp_path / "crlf.fa")
+    with open(crlf, "w", newline="") as fh:
+        fh.write(">x\r\n" + "".join(seqs["chr1"][i:i + 70] + "\r\n" for i in range(0, 100_003, 70)) + ">y\r\nACGT\r\n")
+    c = Fasta(crlf)
+    assert isinstance(c.array("x"), _Contig) and c.get_reference_length("x") == 100_003 and c.fetch("y", 0, 9) == "ACGT"
+    pi = str(tmp_path / "indexed.fa")
+    write_fasta(pi, seqs, width=60, index=True)
+    fi = Fasta(pi)
+    want = np.frombuffer(seqs["chr1"].encode(), np.uint8)
+    idx = rng.integers(0, 100_003, size=5000)
+    for reader in (f, c, fi):
+        a = reader.array("x" if reader is c else "chr1")
+        assert len(a) == 100_003 and np.array_equal(a[idx], want[idx]) and a.tobytes() == want.tobytes()
+        for lo, hi in ((0, 0), (0, 1), (59, 61), (60, 120), (100_000, 100_003), (100_003, 100_010), (5, 99_999)):
+            assert a[lo:hi].tobytes() == want[lo:hi].tobytes(), (lo, hi)
+        with pytest.raises(IndexError):
+            a[np.array([100_003])]
+    assert fi.references == list(seqs) and all(fi.fetch(k, 0, len(v) + 5) == v for k, v in seqs.items())
+    # an index that does not fit the file (or is older than it) is not trusted
+    with open(pi + ".fai", "w") as fh:
+        fh.write("chr1\t999999999\t6\t60\t61\n")
+    assert Fasta(pi).fetch("chr2", 0, 100) == seqs["chr2"]
 
 
 def test_one_pass_boundary_walk_equals_the_run_index(tmp_path):

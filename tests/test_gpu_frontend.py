@@ -271,6 +271,56 @@ def test_device_inflater_equals_the_host_one(gpu_ctx, tmp_path):
         L.strk_dbam_close(h)
 
 
+def test_file_upload_equals_the_buffer_upload(gpu_ctx, tmp_path):
+    """strk_dbam_inflate_file (the library reads the file: ring of pinned pieces, copies as they come in, headers walked
+    meanwhile) against the bytes that went in: a file of several pieces whose blocks straddle the piece ends, block lengths
+    that do not divide the piece size, an empty file, a truncated one, a missing one."""
+    import ctypes as C
+    import os
+    from strkit_amd import _lib
+    from strkit_amd.frontend.bam import _bgzf_blocks
+    rng = np.random.default_rng(5)
+    raw = rng.integers(0, 24, size=44_000_000, dtype=np.uint8)         # ~1.7x compressible: ~26 MB file, four pieces
+    raw[1_000_000:3_000_000] = 7                                         # a stretch of tiny blocks' worth of repeats
+    comp = _bgzf_blocks(raw.tobytes())
+    assert len(comp) > 3 * (8 << 20)
+    path = str(tmp_path / "big.bgzf")
+    with open(path, "wb") as fh:
+        fh.write(comp)
+    L = _lib.load()
+    h = C.c_void_p()
+    _lib.check(L.strk_dbam_open(0, C.byref(h)))
+    try:
+        for threads in (0, 1, 3):
+            nc = C.c_int64(0)
+            n = L.strk_dbam_inflate_file(h, os.fsencode(path), threads, C.byref(nc))
+            assert n == raw.size and nc.value == len(comp), (n, L.strk_last_error())
+            got = np.empty(raw.size, np.uint8)
+            _lib.check(L.strk_dbam_download(h, 0, raw.size, got.ctypes.data))
+            assert np.array_equal(got, raw)
+        # virtual offsets resolve as after the buffer upload
+        arr = np.frombuffer(comp, np.uint8)
+        nxt = C.c_int64(0)
+        voff = np.array([0, 5, (len(comp) - 28) << 16], np.uint64)
+        a, b = np.empty(3, np.int64), np.empty(3, np.int64)
+        _lib.check(L.strk_dbam_voffsets(h, voff.ctypes.data, 3, a.ctypes.data))
+        assert L.strk_dbam_inflate(h, arr.ctypes.data, arr.size, 0, 1 << 40, C.byref(nxt)) == raw.size
+        _lib.check(L.strk_dbam_voffsets(h, voff.ctypes.data, 3, b.ctypes.data))
+        assert np.array_equal(a, b) and a[0] == 0 and a[1] == 5 and a[2] == raw.size
+        empty = str(tmp_path / "empty.bgzf")
+        open(empty, "wb").close()
+        assert L.strk_dbam_inflate_file(h, os.fsencode(empty), 0, None) == 0
+        cut = str(tmp_path / "cut.bgzf")
+        with open(cut, "wb") as fh:
+            fh.write(comp[:(8 << 20) + 1000])
+        assert L.strk_dbam_inflate_file(h, os.fsencode(cut), 0, None) < 0 and b"truncated" in L.strk_last_error()
+        assert L.strk_dbam_inflate_file(h, os.fsencode(str(tmp_path / "none.bgzf")), 0, None) < 0
+        # and the object still works afterwards
+        assert L.strk_dbam_inflate_file(h, os.fsencode(path), 2, None) == raw.size
+    finally:
+        L.strk_dbam_close(h)
+
+
 def test_device_front_end_gives_the_host_report(gpu_ctx, tmp_path):
     """DeviceBam (inflate, record scan, read extraction and names on the GPU; the bases never leave it) against the host
     readers: the same records, the same extracted triples, the same report; noisy reads with low-quality bases and
