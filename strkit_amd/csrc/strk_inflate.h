@@ -52,6 +52,10 @@ struct Tables {           // 320 bytes per stream: LDS on the device
     uint8_t lsym[288];    // literal/length symbols sorted by (code length, symbol), low eight bits
     uint8_t dsym[32];     // distance symbols, likewise (whole); the code-length code's while a block header is read
 };
+#ifndef STRK_INF_LITERAL_RUN
+#define STRK_INF_LITERAL_RUN 4
+#endif
+constexpr int kLiteralRun = STRK_INF_LITERAL_RUN;
 constexpr int kLensBytes = 19 + 286 + 30 + 1;   // code lengths while a block header is being read (global scratch on the device)
 
 struct Code {             // one canonical code: registers on the device (every index is a constant after unrolling)
@@ -157,13 +161,17 @@ STRK_INF_HD int read_dynamic(Stream& s, Tables* t, uint8_t* lens, Code* ll, Code
     refill(s);
     const int nlen = (int)take(s, 5) + 257, ndist = (int)take(s, 5) + 1, ncode = (int)take(s, 4) + 4;
     if (nlen > 286 || ndist > 30) return kErrBadLengths;
-    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    // the order of the code-length code's lengths: 16 17 18 0 8 7 9 6 10 5 11 4 | 12 3 13 2 14 1 15, five bits each
+    const uint64_t order_lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 |
+                              10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+    const uint64_t order_hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
     STRK_INF_LOOP
     for (int i = 0; i < 19; ++i) lens[i] = 0;
     STRK_INF_LOOP
     for (int i = 0; i < ncode; ++i) {
         if (s.cnt < 3) refill(s);
-        lens[order[i]] = (uint8_t)take(s, 3);
+        const int at = (int)((i < 12 ? order_lo >> (5 * i) : order_hi >> (5 * (i - 12))) & 31);
+        lens[at] = (uint8_t)take(s, 3);
     }
     // the code-length code: its words in the distance code's registers, its symbols in the distance slots, until the real
     // distance code is built
@@ -219,11 +227,8 @@ STRK_INF_HD int set_fixed(Tables* t, uint8_t* lens, Code* ll, Code* dl) {
 // Inflates one raw deflate stream of `in_len` bytes into exactly `out_len` bytes.  `in` must be readable up to in_len + 16.
 // `lens`: kLensBytes of scratch.
 STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int out_len, Tables* t, uint8_t* lens) {
-    const uint16_t lbase_tab[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    const uint8_t lext_tab[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    const uint16_t dbase_tab[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
-                                    4097, 6145, 8193, 12289, 16385, 24577};
-    const uint8_t dext_tab[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    // The base values and extra-bit counts of the length and distance symbols (RFC 1951 3.2.5) are computed, not looked up:
+    // a table indexed by a lane's own symbol would be a load from memory, two of them in a row for every match.
     Stream s;
     s.p = in; s.end = in + in_len; s.buf = 0; s.cnt = 0;
     load_ahead(s);
@@ -249,7 +254,35 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
             // a run of a short pattern) is completed by doubling the pattern, and whole words are stored even when fewer
             // bytes belong to the match — what lies behind it is written again by the tokens that follow (never past the
             // end of the block)
-            if (copy_dist >= 128 && copy_len > 32 && pos + 128 <= out_len) {
+            if (copy_dist >= 264 && copy_len > 128 && pos + 264 <= out_len) {
+                // (the longest matches in one trip as well: the slowest lane of a wave sets the pace of this loop)
+                uint64_t w[33];
+                const uint8_t* src = out + pos - copy_dist;
+                STRK_INF_UNROLL
+                for (int k = 0; k < 33; ++k) memcpy(&w[k], src + 8 * k, 8);
+                STRK_INF_UNROLL
+                for (int k = 0; k < 33; ++k) memcpy(out + pos + 8 * k, &w[k], 8);
+                pos += copy_len; copy_len = 0;            // (a match has at most 258 bytes)
+            } else if (copy_dist < 8 && pos + 8 <= out_len) {
+                // a run of a short pattern: one load, then every further word comes from the word before it (its last
+                // `distance` bytes, doubled up to eight) — stores only, nothing to wait for
+                uint64_t w;
+                memcpy(&w, out + pos - copy_dist, 8);
+                const int keep = 8 * copy_dist, drop = 64 - keep;
+                w <<= drop;
+                for (;;) {
+                    w >>= drop;                               // the pattern's `distance` bytes, low
+                    w |= w << keep;                           // 2 x distance bytes (distance >= 4: done)
+                    if (copy_dist < 4) {
+                        w |= w << (2 * keep);                 // 4 x distance
+                        if (copy_dist < 2) w |= w << 32;      // 8 x 1
+                    }
+                    memcpy(out + pos, &w, 8);
+                    const int n = copy_len < 8 ? copy_len : 8;
+                    pos += n; copy_len -= n;
+                    if (copy_len <= 0 || pos + 8 > out_len) break;
+                }
+            } else if (copy_dist >= 128 && copy_len > 32 && pos + 128 <= out_len) {
                 // (a long match: sixteen loads in flight, one trip to memory for 128 bytes)
                 uint64_t w[16];
                 const uint8_t* src = out + pos - copy_dist;
@@ -269,12 +302,6 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
             } else if (pos + 8 <= out_len) {
                 uint64_t w;
                 memcpy(&w, out + pos - copy_dist, 8);
-                if (copy_dist < 8) {
-                    int have = copy_dist;                      // valid bytes of w
-                    w &= (1ull << (8 * have)) - 1;
-                    STRK_INF_LOOP
-                    while (have < 8) { w |= w << (8 * have); have *= 2; }
-                }
                 memcpy(out + pos, &w, 8);
                 const int n = copy_len < 8 ? copy_len : 8;
                 pos += n; copy_len -= n;
@@ -312,9 +339,11 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
             in_block = true;
             continue;
         }
-        int sym, len;
+        int sym = -1, len;
         uint32_t v, w;
-        for (;;) {
+        // (at most kLiteralRun literals per round: a lane with a long run goes round again — its phases (1) and (3) are
+        // empty — instead of keeping the lanes that have reached their next match waiting)
+        for (int lit = 0; lit < kLiteralRun; ++lit) {
             if (s.cnt < 48) {
                 refill(s);
                 if (s.p - 8 > s.end) return kErrOverrun;     // the stream ran past its payload
@@ -334,10 +363,15 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
                 pos += 8; ob = 0; on = 0;
             }
         }
+        if (sym < 256) continue;                          // the run goes on
         if (sym == 256) { in_block = false; continue; }
         flush();
         if (sym > 285) return kErrBadCode;
-        const int mlen = lbase_tab[sym - 257] + (int)take(s, lext_tab[sym - 257]);
+        // lengths: 257..264 -> 3..10; from 265 on four symbols share a number of extra bits e = 1, 2, ...: base =
+        // ((4 + (sym - 265) % 4) << e) + 3; 285 -> 258
+        const int le = sym < 265 || sym == 285 ? 0 : (sym - 261) >> 2;
+        const int lb = sym < 265 ? sym - 254 : sym == 285 ? 258 : ((4 + ((sym - 265) & 3)) << le) + 3;
+        const int mlen = lb + (int)take(s, le);
         v = bitrev15((uint32_t)s.buf);
         w = code_word(v, dl);
         len = (int)(w >> 28);
@@ -345,7 +379,10 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
         const int dsymv = t->dsym[code_at(v, w)];
         s.buf >>= len; s.cnt -= len;
         if (dsymv > 29) return kErrBadCode;
-        const int dist = dbase_tab[dsymv] + (int)take(s, dext_tab[dsymv]);
+        // distances: 0..3 -> 1..4; from 4 on two symbols share e = 1, 2, ... extra bits: base = ((2 + d % 2) << e) + 1
+        const int de = dsymv < 4 ? 0 : (dsymv >> 1) - 1;
+        const int db = dsymv < 4 ? dsymv + 1 : ((2 + (dsymv & 1)) << de) + 1;
+        const int dist = db + (int)take(s, de);
         if (dist > pos) return kErrBadDistance;
         if (pos + mlen > out_len) return kErrSize;
         copy_len = mlen; copy_dist = dist;

@@ -488,6 +488,21 @@ def test_device_inflater_code_on_the_host_equals_zlib(tmp_path):
     rng = np.random.default_rng(4)
     payloads = [b"", b"A", bytes(rng.integers(256, size=40000, dtype=np.uint8)), b"ACGT" * 9000, bytes(60000),
                 bytes(rng.integers(33, 74, size=65000, dtype=np.uint8))]
+    # runs of every short period and matches of every length at short and long distances, up to the last byte of the block
+    # (the copy paths of the decoder: pattern fill from registers, 8 / 32 / 128 / 264 bytes per trip, byte-wise tail)
+    runs = bytearray()
+    for period in range(1, 41):
+        pat = bytes(rng.integers(256, size=period, dtype=np.uint8))
+        for reps in (3, 11, 40, 300 // period + 2):
+            runs += pat * reps + bytes(rng.integers(256, size=int(rng.integers(1, 9)), dtype=np.uint8))
+    far = bytearray(bytes(rng.integers(256, size=3000, dtype=np.uint8)))
+    for ln in list(range(3, 40)) + [63, 64, 65, 127, 128, 129, 130, 200, 257, 258, 259, 300, 600]:
+        for back in (ln, ln + 1, 31, 32, 33, 127, 128, 129, 263, 264, 265, 2000):
+            if back <= len(far) and back >= 1:
+                far += bytes(far[len(far) - back + i % back] if i >= back else far[len(far) - back + i] for i in range(ln)) if back < ln \
+                    else far[len(far) - back:len(far) - back + ln]
+                far += bytes(rng.integers(256, size=int(rng.integers(0, 4)), dtype=np.uint8))
+    payloads += [bytes(runs[:65000]), bytes(far[:65000]), bytes(far[:60000]) + b"\x07" * 300, b"ab" * 150 + b"xyz" * 100]
     for raw in payloads:
         for level, strategy in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_FIXED), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_HUFFMAN_ONLY),
                                 (4, zlib.Z_RLE)):
