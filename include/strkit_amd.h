@@ -280,6 +280,8 @@ int strk_dbam_download(strk_dbam* d, int64_t off, int64_t n, uint8_t* out);
 int strk_dbam_download_seqs(strk_dbam* d, int64_t n, uint8_t* out);
 /* HIP-event time (ms) of all kernels the object has launched so far (inflation, scan, extraction) */
 double strk_dbam_kernel_ms(strk_dbam* d);
+/* wall-clock stages (ms) of the last strk_dbam_inflate_file: buffers (device + pinned ring), read + upload, inflation */
+void strk_dbam_file_ms(strk_dbam* d, double* out3);
 /* device address and size of the decompressed stream (valid until the next strk_dbam_inflate / strk_dbam_close) */
 void* strk_dbam_data(strk_dbam* d, int64_t* n_bytes);
 /* BAM virtual offsets (block offset << 16 | offset in the block) -> offsets in the decompressed stream (-1: not in it) */

@@ -3,12 +3,15 @@ parse_last_column) and the block builder of load_loci (loci.py:170-215, 249-300)
 blocks of at most 200 that stay on one contig and whose neighbours are at most 20 000 bases apart."""
 from __future__ import annotations
 
+import functools
+import re
 from dataclasses import dataclass
 from typing import Iterable, Iterator
 
 __all__ = ["Locus", "LocusValidationError", "valid_motif", "validate_locus", "parse_loci_bed", "parse_last_column",
            "load_loci", "normalize_contig", "resolve_contig", "MAX_BLOCK_SIZE", "MAX_BLOCK_INTER_READ_DIST"]
 
+_ID_MOTIF = re.compile(r"[Ii][Dd]=([^;=\s]+);[Mm][Oo][Tt][Ii][Ff]=([^;=\s]+)$")
 _IUPAC_MOTIF_LETTERS = frozenset("ACGTRYSWKMBDHVN")   # loci.py:30: nucleotide codes, no 'X', no lower case
 MAX_BLOCK_SIZE = 200                                   # loci.py:193
 MAX_BLOCK_INTER_READ_DIST = 20000                      # loci.py:194
@@ -70,6 +73,7 @@ class Locus:
         return f"locus {self.t_idx} (id={self.locus_id}): {self.contig}:{self.left_coord}-{self.right_coord} [{self.motif}]"
 
 
+@functools.lru_cache(maxsize=4096)
 def valid_motif(motif: str) -> bool:
     return len(motif) > 0 and all(ch in _IUPAC_MOTIF_LETTERS for ch in motif)
 
@@ -97,6 +101,9 @@ def parse_last_column(t_idx: int, val: str) -> dict:
     around `=` and after `;` ignored); the motif is upper-cased, the default id is ``locus<t_idx>``."""
     if ";" not in val and "=" not in val:
         return {"id": f"locus{t_idx}", "motif": val}
+    m = _ID_MOTIF.match(val)                             # the common spelling, without blanks: nothing to strip
+    if m:
+        return {"id": m.group(1), "motif": m.group(2).upper()}
     hint = "BED catalog: last column must either be motif or ID=locusID;MOTIF=motif"
     bad = LocusValidationError(f"BED catalog format error: could not parse last column on line {t_idx}: {val}", hint)
     out = {"id": f"locus{t_idx}"}

@@ -352,6 +352,9 @@ class DeviceBam(_Records):
         t0 = time.perf_counter()
         tot = L.strk_dbam_inflate_file(h, os.fsencode(path), 0, None)
         tm["upload_inflate_s"] = round(time.perf_counter() - t0, 4)
+        ms = (C.c_double * 3)()
+        L.strk_dbam_file_ms(h, ms)
+        tm["buffers_s"], tm["read_upload_s"], tm["inflate_s"] = (round(x / 1e3, 4) for x in ms)
         if tot < 0:
             self.close()
             _lib.check(int(tot))
@@ -383,7 +386,7 @@ class DeviceBam(_Records):
         starts = np.unique(np.concatenate(starts)).astype(np.int64)
         tm["header_index_s"] = round(time.perf_counter() - t0 - tm["upload_inflate_s"], 4)
         t1 = time.perf_counter()
-        cap = self.n_bytes // 4096 + 4096
+        cap = 0                                                 # (capacity 0: the count alone, the first of the scan's two passes)
         while True:
             self._set_arrays(cap)
             self.l_name = np.zeros(cap, np.int32)
