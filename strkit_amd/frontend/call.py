@@ -242,7 +242,9 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
             raise ValueError("front_end must be auto, device or host")
         has_index = os.path.exists(bam + ".bai") or os.path.exists(os.path.splitext(bam)[0] + ".bai")
         use_device = front_end == "device" or (front_end == "auto" and os.path.getsize(bam) < (24 << 30) and not _distributed())
-        bam = DeviceBam(bam) if use_device else (IndexedBam(bam) if has_index else NativeBam(bam))
+        # (the device of the rank, as _lib.default_context picks it: one process per GPU)
+        dev = int(os.environ.get("STRKIT_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        bam = DeviceBam(bam, device=dev) if use_device else (IndexedBam(bam) if has_index else NativeBam(bam))
     t_open = time.perf_counter() - t_open       # device reader: upload + inflation + record scan of the whole file
     ref = Fasta(ref) if isinstance(ref, str) else ref
     t0 = time.perf_counter()
