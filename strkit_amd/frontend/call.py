@@ -474,6 +474,12 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = Non
         results.extend(rows)
         n_depth += n
 
+    # The report is hundreds of thousands of small dicts that reference nothing but strings and numbers: the cyclic collector
+    # finds nothing in them and costs a third of the time it takes to build them (it runs every 700 new containers, and its
+    # older generations grow with the report).  It is paused while the blocks run.
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()
     if pool is not None:
         # block-wise access: the records of block k + 1 are inflated (all host cores, outside the GIL) while block k is
         # being called; memory holds three blocks' worth of the alignment file, never the file
@@ -488,9 +494,15 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = Non
                 safe(block, records)
         finally:
             pool.shutdown(wait=True)
+            if gc_was_on:
+                gc.enable()
     else:
-        for block in blocks:
-            safe(block, bam)
+        try:
+            for block in blocks:
+                safe(block, bam)
+        finally:
+            if gc_was_on:
+                gc.enable()
     results.sort(key=lambda r: r["locus_index"])
     return results, n_depth, tm
 
@@ -716,14 +728,15 @@ def _call_block_native(block, bam, ref: Fasta, opts: CallOptions, ctx, tm, ref_d
     ws = ((L + tlwf - 2.0) / (L - tlwf + 1.0)).tolist()
     realn = [bool(alt) and int(it) in alt for it in ok_items[kept]] if alt else None
     first = np.concatenate(([0], np.cumsum(n_kept))).tolist()
+    # the read records of the whole block in one comprehension (values as locals: no indexing), then a dict per locus
+    recs = [{"s": s_, "cn": c_, "w": w_, "sc": q_, "sl": l_} for s_, c_, w_, q_, l_ in zip(strands, cns, ws, scs, sls)]
+    if realn is not None:
+        for k, r_ in enumerate(realn):
+            if r_:
+                recs[k]["realn"] = True
     for li, (locus, rd) in enumerate(live):
         a, b = first[li], first[li + 1]
-        if realn is None:
-            reads = {names[k]: {"s": strands[k], "cn": cns[k], "w": ws[k], "sc": scs[k], "sl": sls[k]} for k in range(a, b)}
-        else:
-            reads = {names[k]: {"s": strands[k], "cn": cns[k], "w": ws[k], "sc": scs[k], "sl": sls[k],
-                                **({"realn": True} if realn[k] else {})} for k in range(a, b)}
-        results.append(_locus_row(locus, rd, reads, opts))
+        results.append(_locus_row(locus, rd, dict(zip(names[a:b], recs[a:b])), opts))
     tm["report_s"] = tm.get("report_s", 0.0) + time.perf_counter() - t_a
     return results, int(len(kept))
 
