@@ -274,6 +274,10 @@ int64_t strk_dbam_inflate(strk_dbam* d, const uint8_t* comp, int64_t n_comp, int
  * inflated by one launch at the end.  *n_comp (may be NULL) = size of the file.  Returns the decompressed bytes or a negative
  * STRK_E_* code. */
 int64_t strk_dbam_inflate_file(strk_dbam* d, const char* path, int threads, int64_t* n_comp);
+/* The same for the BGZF blocks in the file's bytes [coff_lo, coff_hi): both must be block boundaries (what the .bai's virtual
+ * offsets >> 16 are); coff_hi < 0 or past the end = up to the end of the file.  A file whose decompressed form does not fit in
+ * device memory is walked span by span with it (frontend.DeviceBam, streamed mode). */
+int64_t strk_dbam_inflate_file_range(strk_dbam* d, const char* path, int64_t coff_lo, int64_t coff_hi, int threads, int64_t* n_comp);
 /* bytes [off, off + n) of the decompressed stream -> host (headers, a single record for realignment, tests) */
 int strk_dbam_download(strk_dbam* d, int64_t off, int64_t n, uint8_t* out);
 /* the first n bytes of the bases of the last strk_dbam_extract -> host (tests) */

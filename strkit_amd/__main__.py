@@ -20,8 +20,11 @@ def main(argv=None) -> int:
     c.add_argument("--max-reads", type=int, default=250)
     c.add_argument("--realign", action="store_true")
     c.add_argument("--front-end", choices=("auto", "device", "host"), default="auto",
-                   help="where the alignment file is inflated, scanned and cut: on the GPU (needs about six times the file in device "
-                        "memory) or on the host cores, block by block through the .bai; auto = device for files below 24 GB")
+                   help="where the alignment file is inflated, scanned and cut: on the GPU (whole below 24 GB: about six times the "
+                        "file in device memory; larger files with a .bai in spans) or on the host cores, block by block through "
+                        "the .bai; auto = device in a single-process run")
+    c.add_argument("--span-mb", type=int, default=4096,
+                   help="device front end, files of 24 GB and more: compressed megabytes of the file that go through device memory at a time")
     c.add_argument("--respect-ref", action="store_true")
     # same names as `strkit call` (strkit/entry.py:20-342); --seed is accepted for command-line compatibility (the
     # per-read path has no random component), --processes sizes the locus blocks as the reference does (loci.py:193)
@@ -47,7 +50,7 @@ def main(argv=None) -> int:
     rep = call_sample(a.read_file, a.ref, a.loci, flank_size=a.flank_size, realign=a.realign,
                       min_avg_phred=a.min_avg_phred, max_reads=a.max_reads, respect_ref=a.respect_ref,
                       sample_id=a.sample_id, processes=a.processes, rc_params=rc,
-                      min_read_align_score=a.min_read_align_score, front_end=a.front_end)
+                      min_read_align_score=a.min_read_align_score, front_end=a.front_end, span_bytes=a.span_mb << 20)
     if world > 1:
         import torch.distributed as dist
         rank0 = dist.get_rank() == 0

@@ -229,11 +229,13 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
                 min_avg_phred: int = MIN_AVG_PHRED, max_reads: int = MAX_READS, respect_ref: bool = False,
                 sample_id: str | None = None, ctx: _lib.Context | None = None, processes: int = 1,
                 rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE,
-                tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL, front_end: str = "auto") -> dict:
-    """`front_end` (for a `bam` given as a path): "device" = the file is inflated, scanned and cut on the GPU (DeviceBam: its
-    decompressed form, about six times the file, has to fit in device memory next to the workspace), "host" = block-wise
-    through the .bai on the host cores (IndexedBam) or, without an index, the whole stream (NativeBam), "auto" = "device"
-    for a file below 24 GB in a single-process run, else "host"."""
+                tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL, front_end: str = "auto",
+                span_bytes: int = 4 << 30) -> dict:
+    """`front_end` (for a `bam` given as a path): "device" = the file is inflated, scanned and cut on the GPU (DeviceBam) —
+    whole when it is below 24 GB (its decompressed form, about six times the file, stays in device memory next to the
+    workspace), else, with a .bai, in spans of at most `span_bytes` compressed bytes that follow the catalog; "host" =
+    block-wise through the .bai on the host cores (IndexedBam) or, without an index, the whole stream (NativeBam); "auto" =
+    "device" in a single-process run (a file of 24 GB or more needs its index for that), else "host"."""
     t_open = time.perf_counter()
     own_reader = isinstance(bam, str)
     if isinstance(bam, str):
@@ -241,10 +243,14 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
         if front_end not in ("auto", "device", "host"):
             raise ValueError("front_end must be auto, device or host")
         has_index = os.path.exists(bam + ".bai") or os.path.exists(os.path.splitext(bam)[0] + ".bai")
-        use_device = front_end == "device" or (front_end == "auto" and os.path.getsize(bam) < (24 << 30) and not _distributed())
+        small = os.path.getsize(bam) < (24 << 30)               # decompressed (about six times that) it fits in HBM
+        use_device = front_end == "device" or (front_end == "auto" and (small or has_index) and not _distributed())
         # (the device of the rank, as _lib.default_context picks it: one process per GPU)
         dev = int(os.environ.get("STRKIT_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-        bam = DeviceBam(bam, device=dev) if use_device else (IndexedBam(bam) if has_index else NativeBam(bam))
+        if use_device:                                            # a larger file goes through HBM span by span (needs the index)
+            bam = DeviceBam(bam, device=dev, span_bytes=None if small or not has_index else span_bytes)
+        else:
+            bam = IndexedBam(bam) if has_index else NativeBam(bam)
     t_open = time.perf_counter() - t_open       # device reader: upload + inflation + record scan of the whole file
     ref = Fasta(ref) if isinstance(ref, str) else ref
     t0 = time.perf_counter()
@@ -494,6 +500,19 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = Non
                 safe(block, records)
         finally:
             pool.shutdown(wait=True)
+            if gc_was_on:
+                gc.enable()
+    elif isinstance(bam, DeviceBam) and bam.streamed:
+        # a file larger than device memory: span by span through HBM (DeviceBam.plan / load_span)
+        try:
+            tm["load_s"] = 0.0
+            for contig, beg, end, group in bam.plan([b for blk in blocks for b in _one_contig_blocks(blk)]):
+                t0 = time.perf_counter()
+                bam.load_span(contig, beg, end)
+                tm["load_s"] += time.perf_counter() - t0
+                for block in group:
+                    safe(block, bam)
+        finally:
             if gc_was_on:
                 gc.enable()
     else:

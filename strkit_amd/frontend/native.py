@@ -340,14 +340,28 @@ class DeviceBam(_Records):
     index walks the record chain to the next entry) and only their per-record fields come back to the host, where the
     interval queries of _Records run on them as for any other reader.  Read extraction (extract_reads) and read names go
     through the device as well, and the extracted bases never leave it: strk_count_loci_dseqs counts them where they are.
-    A record comes to the host only when somebody asks for it as a segment (soft-clipped reads on their way to realignment)."""
+    A record comes to the host only when somebody asks for it as a segment (soft-clipped reads on their way to realignment).
 
-    def __init__(self, path: str, index: str | None = None, device: int = 0):
+    `span_bytes` (needs the .bai): STREAMED mode for a file whose decompressed form does not fit in device memory — a 30x
+    whole-genome file is 60-100 GB compressed, six times that inflated.  Nothing is loaded at first; `plan(blocks)` groups the
+    catalog blocks of a contig into spans of at most that many compressed bytes, `load_span` reads one span of the file
+    (strk_dbam_inflate_file_range: the BGZF blocks between two offsets the linear index gives), inflates and scans it on the
+    device, and the object then serves that span exactly as it serves a whole file.  call_blocks walks the spans in turn."""
+
+    def __init__(self, path: str, index: str | None = None, device: int = 0, span_bytes: int | None = None):
         self.path = path
         L = _lib.load()
         h = C.c_void_p()
         _lib.check(L.strk_dbam_open(int(device), C.byref(h)))
         self._h = h
+        self.streamed = span_bytes is not None
+        if self.streamed:
+            try:
+                self._init_streamed(path, index, int(span_bytes))
+            except Exception:
+                self.close()
+                raise
+            return
         tm = self.open_stage_s = {}
         t0 = time.perf_counter()
         tot = L.strk_dbam_inflate_file(h, os.fsencode(path), 0, None)
@@ -386,23 +400,142 @@ class DeviceBam(_Records):
         starts = np.unique(np.concatenate(starts)).astype(np.int64)
         tm["header_index_s"] = round(time.perf_counter() - t0 - tm["upload_inflate_s"], 4)
         t1 = time.perf_counter()
+        self._scan(starts)
+        tm["scan_s"] = round(time.perf_counter() - t1, 4)
+        t1 = time.perf_counter()
+        self._build_index()
+        tm["record_index_s"] = round(time.perf_counter() - t1, 4)
+
+    def _scan(self, starts: np.ndarray) -> None:
+        """Record scan of the resident stretch from the entry points `starts`: the per-record arrays, in file order."""
+        L = _lib.load()
         cap = 0                                                 # (capacity 0: the count alone, the first of the scan's two passes)
         while True:
             self._set_arrays(cap)
             self.l_name = np.zeros(cap, np.int32)
-            n = L.strk_dbam_scan(h, starts.ctypes.data, starts.size, cap, *self._scan_ptrs(), self.l_name.ctypes.data)
+            n = L.strk_dbam_scan(self._h, starts.ctypes.data, starts.size, cap, *self._scan_ptrs(), self.l_name.ctypes.data)
             if n < 0:
                 self.close()
                 _lib.check(int(n))
             if n <= cap:
                 break
             cap = int(n)
-        tm["scan_s"] = round(time.perf_counter() - t1, 4)
-        t1 = time.perf_counter()
         self._trim(int(n))
         self.l_name = self.l_name[:int(n)]
+
+    # ---- streamed mode -------------------------------------------------------------------------------------------------
+    def _init_streamed(self, path: str, index: str | None, span_bytes: int) -> None:
+        ib = IndexedBam(path, index)             # header through the host (the first blocks), the 16 kb linear index
+        self.header_text, self.contigs, self._lin = ib.header_text, ib.contigs, ib._lin
+        del ib
+        self.span_bytes = max(int(span_bytes), 1 << 20)
+        self._file_size = os.path.getsize(path)
+        voff = np.unique(np.concatenate([x[x != 0] for x in self._lin] or [np.zeros(0, np.uint64)]).astype(np.uint64))
+        self._voffs = voff                                        # every record start the index knows, in file order
+        self._block_starts = np.unique((voff >> np.uint64(16)).astype(np.int64))     # block boundaries among them
+        self._span = None                                         # (tid, beg, end) of what is resident
+        self.n_bytes = 0
+        self.data = None
+        self._set_arrays(0)
+        self.l_name = np.zeros(0, np.int32)
         self._build_index()
-        tm["record_index_s"] = round(time.perf_counter() - t1, 4)
+        self.open_stage_s = {"spans": 0, "load_s": 0.0, "compressed_mb": 0.0}
+
+    def _tid(self, contig: str) -> int:
+        names = self.references
+        name = resolve_contig(names, contig)
+        return names.index(name) if name is not None else -1
+
+    def _coff_range(self, tid: int, beg: int, end: int, margin: int) -> tuple[int, int, int] | None:
+        """(compressed offset of the first block, of the end, virtual offset of the first record) for the records of contig
+        `tid` that start before `end` and can overlap [beg, end).  The upper end is a guess — the linear index says where the
+        records that OVERLAP a window begin, not where those that start in it do: load_span checks it and widens `margin`."""
+        lin = self._lin[tid] if 0 <= tid < len(self._lin) else np.zeros(0, np.uint64)
+        w = max(0, int(beg)) >> 14
+        nz = np.flatnonzero(lin[w:]) if w < len(lin) else np.zeros(0, np.int64)
+        if nz.size == 0:
+            return None
+        v_lo = int(lin[w + int(nz[0])])
+        w2 = ((int(end) + margin) >> 14) + 1
+        later = lin[w2:][lin[w2:] != 0] if w2 < len(lin) else np.zeros(0, np.uint64)
+        if later.size:
+            cand = int(later[0]) >> 16
+        else:                                                    # the contig ends: up to where the next one begins
+            cand = -1
+            for t in range(tid + 1, len(self._lin)):
+                nzt = self._lin[t][self._lin[t] != 0]
+                if nzt.size:
+                    cand = int(nzt[0]) >> 16
+                    break
+        if cand < 0:
+            return v_lo >> 16, self._file_size, v_lo
+        k = int(np.searchsorted(self._block_starts, max(cand, v_lo >> 16), side="right"))    # the block after it
+        hi = int(self._block_starts[k]) if k < self._block_starts.size else self._file_size
+        return v_lo >> 16, hi, v_lo
+
+    def plan(self, blocks: list) -> list[tuple[str, int, int, list]]:
+        """Catalog blocks (one contig each) -> spans (contig, beg, end, blocks) of at most span_bytes compressed bytes, in
+        catalog order; a block that needs more by itself is a span of its own."""
+        spans: list[tuple[str, int, int, list]] = []
+        cur = None
+        for block in blocks:
+            contig = block[0].contig
+            beg = min(l.left_flank_coord for l in block)
+            end = max(l.right_flank_coord for l in block) + 1
+            if cur is not None and cur[0] == contig:
+                nb, ne = min(cur[1], beg), max(cur[2], end)
+                r = self._coff_range(self._tid(contig), nb, ne, 1 << 20)
+                if r is not None and r[1] - r[0] <= self.span_bytes:
+                    cur = (contig, nb, ne, cur[3] + [block])
+                    continue
+            if cur is not None:
+                spans.append(cur)
+            cur = (contig, beg, end, [block])
+        if cur is not None:
+            spans.append(cur)
+        return spans
+
+    def load_span(self, contig: str, beg: int, end: int) -> None:
+        """Makes the records of `contig` that can overlap [beg, end) resident (replacing what was)."""
+        L = _lib.load()
+        t0 = time.perf_counter()
+        tid = self._tid(contig)
+        margin = 1 << 20
+        while True:
+            r = self._coff_range(tid, beg, end, margin) if tid >= 0 else None
+            if r is None:
+                self.n_bytes = 0
+                self._set_arrays(0)
+                self.l_name = np.zeros(0, np.int32)
+                break
+            lo, hi, v_lo = r
+            tot = L.strk_dbam_inflate_file_range(self._h, os.fsencode(self.path), lo, hi, 0, None)
+            if tot < 0:
+                _lib.check(int(tot))
+            self.n_bytes = int(tot)
+            a = int(np.searchsorted(self._voffs, np.uint64(v_lo), side="left"))
+            b = int(np.searchsorted(self._voffs, np.uint64(hi) << np.uint64(16), side="left"))
+            voff = np.ascontiguousarray(self._voffs[a:b])
+            off = np.empty(voff.size, np.int64)
+            _lib.check(L.strk_dbam_voffsets(self._h, voff.ctypes.data, voff.size, off.ctypes.data))
+            starts = np.unique(off[(off >= 0) & (off < self.n_bytes)]).astype(np.int64)
+            self._scan(starts)
+            # complete when the file order has gone past `end` (sorted by position) or the file ended
+            n = self.n_records
+            done = hi >= self._file_size or n == 0
+            if n:
+                lt, lp = int(self.tid[n - 1]), int(self.pos[n - 1])
+                done = done or lt != tid or lp >= end
+            if done or margin > (1 << 34):
+                break
+            margin *= 8                                           # reads longer than the margin lie across the end: further
+        self._build_index()
+        self._span = (tid, int(beg), int(end))
+        st = self.open_stage_s
+        st["spans"] += 1
+        st["load_s"] = round(st["load_s"] + time.perf_counter() - t0, 4)
+        if r is not None:
+            st["compressed_mb"] = round(st["compressed_mb"] + (hi - lo) / 1e6, 1)
 
     def kernel_s(self) -> float:
         """HIP-event time of all the kernels this reader has launched (inflation, record scan, extraction), in seconds."""
@@ -420,7 +553,12 @@ class DeviceBam(_Records):
             pass
 
     def region(self, contig: str, beg: int, end: int, threads: int = 0, slot: int | None = None):
-        """Every record is resident: a region is the reader itself."""
+        """Every record is resident: a region is the reader itself.  (Streamed mode: the span is loaded unless the resident
+        one covers it.)"""
+        if self.streamed:
+            tid = self._tid(contig)
+            if self._span is None or self._span[0] != tid or beg < self._span[1] or end > self._span[2]:
+                self.load_span(contig, beg, end)
         return self
 
     def _download(self, off: int, n: int) -> np.ndarray:

@@ -1,5 +1,6 @@
 """End to end on the device: synthetic BAM + FASTA + catalog -> call_sample -> per-read copy numbers."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -363,5 +364,46 @@ def test_device_front_end_gives_the_host_report(gpu_ctx, tmp_path):
         assert "load_s" not in auto["stage_times"]
         with pytest.raises(ValueError):
             call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"], front_end="gpu")
+    finally:
+        db.close()
+
+
+def test_streamed_device_front_end_gives_the_resident_report(gpu_ctx, tmp_path):
+    """DeviceBam in streamed mode (a file larger than device memory: spans of the file, chosen through the .bai, go through HBM
+    one after the other) against the same file held whole: the same report from many small spans and from one span; a region
+    outside the resident span loads its own."""
+    from strkit_amd.frontend import DeviceBam, Fasta, call_sample, load_loci
+    from strkit_amd.frontend.synth_large import make_dataset_large
+    t = make_dataset_large(str(tmp_path), n_loci=700, depth=8, read_len=8000, seed=23, spacing=9000, procs=4)
+    p = t["paths"]
+    size = os.path.getsize(p["bam"])
+    assert size > (6 << 20)
+    whole = call_sample(p["bam"], p["ref"], p["loci"], front_end="device")
+    assert whole["stage_times"]["front_end"] == "device" and len(whole["results"]) == 700
+    ref = Fasta(p["ref"])
+    for span in (1 << 20, 3 << 20, 1 << 40):
+        db = DeviceBam(p["bam"], span_bytes=span)
+        try:
+            assert db.streamed and db.n_records == 0
+            blocks = load_loci(p["loci"], contigs=db.references)
+            plan = db.plan(blocks)
+            assert sum(len(g[3]) for g in plan) == len(blocks) and (len(plan) > 3 if span < size else len(plan) == 1)
+            rep = call_sample(db, ref, p["loci"])
+            assert db.open_stage_s["spans"] == len(plan)
+        finally:
+            db.close()
+        assert rep["results"] == whole["results"], span
+    # on demand: a region outside the resident span loads its own
+    db = DeviceBam(p["bam"], span_bytes=1 << 20)
+    try:
+        blocks = load_loci(p["loci"], contigs=db.references)
+        last = blocks[-1]
+        lo, hi = last[0].left_flank_coord, last[-1].right_flank_coord + 1
+        r = db.region(last[0].contig, lo, hi)
+        n1 = len(r.fetch_indices(last[0].contig, lo, hi))
+        first = blocks[0]
+        r2 = db.region(first[0].contig, first[0].left_flank_coord, first[0].right_flank_coord + 1)
+        assert n1 > 0 and len(r2.fetch_indices(first[0].contig, first[0].left_flank_coord, first[0].right_flank_coord + 1)) > 0
+        assert db.open_stage_s["spans"] == 2
     finally:
         db.close()
