@@ -265,6 +265,10 @@ int strk_extract_reads(const uint8_t* buf, int64_t n_bytes, int32_t n_items, con
 typedef struct strk_dbam strk_dbam;
 int strk_dbam_open(int device, strk_dbam** out);
 void strk_dbam_close(strk_dbam* d);
+/* A closed reader leaves its two largest device buffers (the decompressed stream, the compressed bytes) to the next reader of
+ * the process instead of freeing them (allocating gigabytes right after freeing them can take longer than inflating the file);
+ * this frees them. */
+void strk_dbam_release_cache(void);
 /* Inflates the consecutive BGZF blocks of `comp` (HOST memory) from byte `coff` on, as many as decompress into at most
  * max_out bytes, into the object's device buffer (one GPU lane per block, CRC checked); *next_coff = offset of the first block
  * not taken.  Returns the decompressed bytes or a negative STRK_E_* code. */

@@ -48,7 +48,7 @@ EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk
            "strk_count_loci_device", "strk_submit_loci_device", "strk_finish", "strk_score_table",
            "strk_score_ref_table", "strk_ref_repeat_count", "strk_ref_repeat_count_batch", "strk_realign", "strk_bam_scan",
            "strk_extract_reads", "strk_bgzf_inflate", "strk_bgzf_inflate_range", "strk_bam_names", "strk_bam_scan_piece",
-           "strk_dbam_open", "strk_dbam_close", "strk_dbam_inflate", "strk_dbam_inflate_file", "strk_dbam_inflate_file_range", "strk_dbam_file_ms", "strk_dbam_download", "strk_dbam_data", "strk_bgzf_inflate_sw",
+           "strk_dbam_open", "strk_dbam_close", "strk_dbam_release_cache", "strk_dbam_inflate", "strk_dbam_inflate_file", "strk_dbam_inflate_file_range", "strk_dbam_file_ms", "strk_dbam_download", "strk_dbam_data", "strk_bgzf_inflate_sw",
            "strk_dbam_download_seqs", "strk_dbam_kernel_ms", "strk_dbam_voffsets", "strk_dbam_scan", "strk_dbam_extract", "strk_dbam_names", "strk_count_loci_dseqs", "strk_read_coords_both")
 
 _lib = None
@@ -122,6 +122,8 @@ def load(build: bool = True):
         L.strk_bgzf_inflate_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int32]
         L.strk_dbam_open.restype = C.c_int
         L.strk_dbam_open.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.strk_dbam_release_cache.restype = None
+        L.strk_dbam_release_cache.argtypes = []
         L.strk_dbam_close.restype = None
         L.strk_dbam_close.argtypes = [C.c_void_p]
         L.strk_dbam_inflate.restype = C.c_int64
