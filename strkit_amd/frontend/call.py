@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import json
 import sys
+import threading
 import time
 from dataclasses import dataclass
 
@@ -26,7 +27,7 @@ from .extract import (LowMeanBaseQual, MIN_AVG_PHRED, get_read_coords_from_cigar
                       get_sequence_data_for_locus)
 from .fasta import Fasta
 from .loci import Locus, load_loci, parse_loci_bed, resolve_contig
-from .native import DeviceBam, IndexedBam, NativeBam, extract_reads, realign_cigar_to_read_alignment
+from .native import DeviceBam, IndexedBam, NativeBam, extract_reads, host_header, realign_cigar_to_read_alignment
 from .output import read_weights
 
 __all__ = ["CallOptions", "call_sample", "call_locus", "call_blocks", "call_blocks_sharded", "deal_locus_blocks", "write_json", "get_locus_with_ref_data", "get_loci_with_ref_data", "MAX_READS"]
@@ -248,17 +249,53 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
         # (the device of the rank, as _lib.default_context picks it: one process per GPU)
         dev = int(os.environ.get("STRKIT_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         if use_device:                                            # a larger file goes through HBM span by span (needs the index)
-            bam = DeviceBam(bam, device=dev, span_bytes=None if small or not has_index else span_bytes)
+            # The file is opened (read, uploaded, inflated, scanned: reader threads and the GPU, no Python) while this thread
+            # loads the catalog and computes the reference side of every locus, which needs neither.  What both need — the
+            # contig names — comes from the file's first blocks, inflated here.
+            path = bam
+            references = [c for c, _ in host_header(path)[1]]
+            opened: list = []
+
+            def open_reader():
+                t_ = time.perf_counter()
+                try:
+                    opened.append(DeviceBam(path, device=dev, span_bytes=None if small or not has_index else span_bytes))
+                except BaseException as e:  # noqa: BLE001  (handed to the caller's thread below)
+                    opened.append(e)
+                opened.append(time.perf_counter() - t_)
+
+            opener = threading.Thread(target=open_reader, name="strkit_amd-open")
+            opener.start()
+            bam = None
         else:
             bam = IndexedBam(bam) if has_index else NativeBam(bam)
-    t_open = time.perf_counter() - t_open       # device reader: upload + inflation + record scan of the whole file
-    ref = Fasta(ref) if isinstance(ref, str) else ref
-    t0 = time.perf_counter()
+    t_open = time.perf_counter() - t_open       # (device reader: replaced below by the time its thread took)
     opts = CallOptions(flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params, min_read_align_score, tie_rule, end_flags)
-    # catalog, alignment file and reference may or may not carry the "chr" prefix (call_locus.py:758 normalize_contig):
-    # a locus is called when its contig exists, under either spelling, in both files
-    both = {c for c in bam.references if resolve_contig(ref.references, c) is not None}
-    blocks = load_loci(loci_file, flank_size, contigs=both, processes=processes)
+    try:
+        ref = Fasta(ref) if isinstance(ref, str) else ref
+        t0 = time.perf_counter()
+        # catalog, alignment file and reference may or may not carry the "chr" prefix (call_locus.py:758 normalize_contig):
+        # a locus is called when its contig exists, under either spelling, in both files
+        both = {c for c in (bam.references if bam is not None else references) if resolve_contig(ref.references, c) is not None}
+        blocks = load_loci(loci_file, flank_size, contigs=both, processes=processes)
+        tm_pre: dict = {}
+        ref_cache = None
+        if bam is None and not _distributed():
+            ref_cache = ref_side_of_blocks(blocks, ref, opts, ctx or _lib.default_context(), tm_pre)
+    except BaseException:
+        if bam is None:                          # do not leave a reader (gigabytes of device memory) behind
+            opener.join()
+            if isinstance(opened[0], DeviceBam):
+                opened[0].close()
+        raise
+    t_wait = 0.0
+    if bam is None:                              # the reader, or what kept it from opening
+        t_w = time.perf_counter()
+        opener.join()
+        t_wait = time.perf_counter() - t_w
+        if isinstance(opened[0], BaseException):
+            raise opened[0]
+        bam, t_open = opened[0], opened[1]
     n_catalog = sum(1 for _ in parse_loci_bed(loci_file))
     n_loaded = sum(len(b) for b in blocks)
     if n_loaded < n_catalog:
@@ -266,7 +303,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
               f"the reference does not have; they are not called", file=sys.stderr)
 
     def run(bl):
-        return call_blocks(bl, bam, ref, opts, ctx)
+        return call_blocks(bl, bam, ref, opts, ctx, ref_cache=ref_cache)
 
     try:
         if _distributed():          # launched under torch.distributed (one rank per GPU): shard the blocks
@@ -278,7 +315,10 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
         if own_reader and isinstance(bam, DeviceBam):
             bam.close()             # gigabytes of device memory: not left to the garbage collector
     errors = tm.pop("errors", [])
+    tm["ref_side_s"] = tm.get("ref_side_s", 0.0) + tm_pre.get("ref_side_s", 0.0)
     tm["open_s"] = t_open
+    if own_reader and isinstance(bam, DeviceBam):
+        tm["open_wait_s"] = t_wait              # what this thread still waited for the reader after catalog + reference side
     tm["front_end"] = "device" if isinstance(bam, DeviceBam) else "host"
     if fe_kernel_s is not None:
         tm["front_end_device_s"] = fe_kernel_s      # inflation + record scan + extraction kernels (HIP events)
@@ -421,7 +461,25 @@ def call_blocks_sharded(blocks, call_fn, ref: Fasta | None = None, respect_ref: 
     return merged, sum(len(r.get("reads") or {}) for r in merged), stage
 
 
-def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = None, ctx=None):
+def ref_side_of_blocks(blocks, ref: Fasta, opts: CallOptions, ctx, tm: dict) -> dict:
+    """Reference side of ALL loci of `blocks`, a few thousand per library call (each of its lock-step rounds is one device launch
+    however many loci take part): {id(locus): reference data or None}.  A chunk that fails is left out — call_blocks' per-block
+    path computes it again and isolates the locus."""
+    ref_cache: dict[int, dict | None] = {}
+    flat = [l for blk in blocks for l in blk]
+    t_a = time.perf_counter()
+    for c0 in range(0, len(flat), 4096):
+        chunk = flat[c0:c0 + 4096]
+        try:
+            for locus, rd in zip(chunk, get_loci_with_ref_data(chunk, ref, opts.respect_ref, ctx)):
+                ref_cache[id(locus)] = rd
+        except (_lib.StrkError, ValueError):
+            pass
+    tm["ref_side_s"] = tm.get("ref_side_s", 0.0) + time.perf_counter() - t_a
+    return ref_cache
+
+
+def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = None, ctx=None, ref_cache: dict | None = None):
     """Worker loop over blocks of loci (strkit/call/call_sample.py:103-197): (results in locus order, reads kept,
     stage times).  An error of the library inside a block is handled the way the reference's worker handles any
     exception of call_locus (call_sample.py:159-166: logged, the locus is dropped, the run goes on): the block is
@@ -450,19 +508,9 @@ def call_blocks(blocks, bam: BamFile, ref: Fasta, opts: CallOptions | None = Non
         pool = ThreadPoolExecutor(1)
         fut = pool.submit(load, blocks[0], 0) if blocks else None
 
-    # reference side of ALL loci first, a few thousand per library call (each of its lock-step rounds is one device launch
-    # however many loci take part); a chunk that fails is left to the per-block path below, which isolates the locus
-    ref_cache: dict[int, dict | None] = {}
-    flat = [l for blk in blocks for l in blk]
-    t_a = time.perf_counter()
-    for c0 in range(0, len(flat), 4096):
-        chunk = flat[c0:c0 + 4096]
-        try:
-            for locus, rd in zip(chunk, get_loci_with_ref_data(chunk, ref, opts.respect_ref, ctx)):
-                ref_cache[id(locus)] = rd
-        except (_lib.StrkError, ValueError):
-            pass
-    tm["ref_side_s"] += time.perf_counter() - t_a
+    # reference side of ALL loci first (unless the caller has it already)
+    if ref_cache is None:
+        ref_cache = ref_side_of_blocks(blocks, ref, opts, ctx, tm)
 
     def safe(block, records):
         nonlocal n_depth

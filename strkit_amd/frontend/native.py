@@ -209,6 +209,25 @@ class _Region(_Records):
     pass
 
 
+def host_header(path: str, comp: np.ndarray | None = None) -> tuple[str, list[tuple[str, int]], int]:
+    """(header text, contigs, offset of the first record in the decompressed stream) of a BAM file, from its first BGZF blocks
+    inflated on the host: what a caller needs (the contig names) before any reader has opened the file."""
+    comp = np.memmap(path, np.uint8, "r") if comp is None else comp
+    L = _lib.load()
+    head = np.empty(1 << 20, np.uint8)
+    nxt = C.c_int64(0)
+    while True:                                  # the header may span several blocks
+        got = L.strk_bgzf_inflate_range(comp.ctypes.data, comp.size, 0, head.ctypes.data, head.size, C.byref(nxt), 1)
+        if got < 0:
+            _lib.check(int(got))
+        try:
+            return _parse_header(head[:int(got)])
+        except (struct.error, IndexError, ValueError):
+            if nxt.value >= comp.size or head.size > (1 << 28):
+                raise ValueError(f"{path}: not a BAM file") from None
+            head = np.empty(head.size * 4, np.uint8)
+
+
 class IndexedBam:
     """Block-wise access to a coordinate-sorted BAM through its .bai index (SAM specification §5.2), the way the reference's
     reader fetches one block of loci at a time (call_sample.py:121): the compressed file is memory-mapped, `region()`
@@ -219,20 +238,7 @@ class IndexedBam:
     def __init__(self, path: str, index: str | None = None):
         self.path = path
         self.comp = np.memmap(path, np.uint8, "r")
-        L = _lib.load()
-        head = np.empty(1 << 20, np.uint8)
-        nxt = C.c_int64(0)
-        while True:                              # the header may span several blocks
-            got = L.strk_bgzf_inflate_range(self.comp.ctypes.data, self.comp.size, 0, head.ctypes.data, head.size, C.byref(nxt), 1)
-            if got < 0:
-                _lib.check(int(got))
-            try:
-                self.header_text, self.contigs, self._first = _parse_header(head[:int(got)])
-                break
-            except (struct.error, IndexError, ValueError):
-                if nxt.value >= self.comp.size or head.size > (1 << 28):
-                    raise ValueError(f"{path}: not a BAM file") from None
-                head = np.empty(head.size * 4, np.uint8)
+        self.header_text, self.contigs, self._first = host_header(path, self.comp)
         index = index or (path + ".bai" if os.path.exists(path + ".bai") else os.path.splitext(path)[0] + ".bai")
         self._lin = self._read_bai(index, len(self.contigs))
 
