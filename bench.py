@@ -167,7 +167,8 @@ def run_e2e(data: dict) -> dict:
     out.update({"read_len": int(data.get("read_len", 0)) or None, "bam_mb": os.path.getsize(paths["bam"]) >> 20,
                 "host_front_end": host, "front_ends_agree": rows_dev == rows_host, "dataset_gen_s": data["gen_s"],
                 "note": "wall_s = opening the alignment file + FASTA + catalog + calling + report rows.  Device front end: open_s = "
-                        "upload + inflation + record scan of the whole file on the GPU, the bases never leave it.  Host front end: load_s "
+                        "read + upload + inflation + record scan of the whole file on the GPU (a thread of its own, beside catalog and "
+                        "reference side: open_wait_s is what the caller still waited), the bases never leave the device.  Host front end: load_s "
                         "(BGZF inflate of a block's records, all cores) runs in a second thread and overlaps calling, load_wait_s is what "
                         "the caller waited for it"})
     shutil.rmtree(data["dir"], ignore_errors=True)

@@ -699,10 +699,16 @@ def _call_block_python(block, bam: BamFile, ref: Fasta, opts: CallOptions, ctx, 
 
 
 def _call_block_native(block, bam, ref: Fasta, opts: CallOptions, ctx, tm, ref_data=None):
-    """One block over the records of a NativeBam / an IndexedBam region: no Python per read before the report.  The
-    overlapping records of all loci come from one vectorised interval query (`fetch_many`), ONE strk_extract_reads call
-    (all host cores) cuts every read of every locus, one device call counts them, numpy filters them; only the rows of
-    the report are built read by read (timed apart as report_s).  (rows, reads kept)"""
+    """One block over the records of a NativeBam / an IndexedBam region / a DeviceBam: no Python per read before the report.
+    The overlapping records of all loci come from one vectorised interval query (`fetch_many`), ONE extraction call cuts every
+    read of every locus, one device call counts them, numpy filters them (_block_device_stage); only the rows of the report
+    are built read by read (_block_report_stage, timed apart as report_s).  (rows, reads kept)"""
+    return _block_report_stage(_block_device_stage(block, bam, ref, opts, ctx, tm, ref_data), opts, tm)
+
+
+def _block_device_stage(block, bam, ref: Fasta, opts: CallOptions, ctx, tm, ref_data=None):
+    """Everything of a block that touches the reader and the device: interval query, extraction, counting, filters, the names
+    of the reads that are kept.  Returns what the report stage needs (or the finished rows when no locus is live)."""
     flank_size = opts.flank_size
     results: list[dict] = []
     t_a = time.perf_counter()
@@ -713,7 +719,7 @@ def _call_block_native(block, bam, ref: Fasta, opts: CallOptions, ctx, tm, ref_d
     live = [(locus, rd) for locus, rd in zip(block, ref_data) if rd is not None]
     results.extend(_locus_dict(locus) for locus, rd in zip(block, ref_data) if rd is None)
     if not live:
-        return results, 0
+        return {"results": results, "live": live}
     lfc = np.array([l.left_flank_coord for l, _ in live], np.int64)
     rfc = np.array([l.right_flank_coord for l, _ in live], np.int64)
     lca = np.array([rd["left_coord_adj"] for _, rd in live], np.int64)
@@ -767,28 +773,42 @@ def _call_block_native(block, bam, ref: Fasta, opts: CallOptions, ctx, tm, ref_d
     t_a = time.perf_counter()
     res, flt = _count(batch, opts, ctx, tm)
     tm["count_s"] += time.perf_counter() - t_a
-    # ---- report rows (call_locus.py:1279-1288,1340-1352) ------------------------------------------------------------
     t_a = time.perf_counter()
     ok_items = np.nonzero(ok)[0]
     read_locus = item_locus[ok]
     keep = flt["keep"] & flt["locus_ok"][read_locus]
     kept = np.nonzero(keep)[0]
-    n_kept = np.bincount(read_locus[kept], minlength=len(live))
     kept_rec = rec[ok_items[kept]]
-    names = bam.names(kept_rec)
-    strands = np.where(bam.flag[kept_rec] & 16, "-", "+").tolist()
-    cns = res["cn"][kept].tolist()
-    scs = [None if x != x else x for x in flt["sc"][kept].tolist()]
-    sls = batch.ntr[kept].tolist()
+    st = {"results": results, "live": live, "rec": rec, "counts": counts, "item_locus": item_locus, "ok_items": ok_items,
+          "read_locus": read_locus, "kept": kept, "kept_rec": kept_rec, "names": bam.names(kept_rec),
+          "minus": (bam.flag[kept_rec] & 16) != 0, "lens_all": bam.l_seq[rec].astype(np.int64), "cn": res["cn"], "sc": flt["sc"],
+          "nfl": batch.nfl, "ntr": batch.ntr, "nfr": batch.nfr, "alt": alt}
+    tm["names_s"] = tm.get("names_s", 0.0) + time.perf_counter() - t_a
+    return st
+
+
+def _block_report_stage(st, opts: CallOptions, tm):
+    """Report rows of a block (call_locus.py:1279-1288,1340-1352) from what _block_device_stage left: Python and numpy only."""
+    results, live = st["results"], st["live"]
+    if not live:
+        return results, 0
+    t_a = time.perf_counter()
+    rec, counts, item_locus, ok_items, read_locus, kept = (st[k] for k in ("rec", "counts", "item_locus", "ok_items", "read_locus", "kept"))
+    names, alt = st["names"], st["alt"]
+    n_kept = np.bincount(read_locus[kept], minlength=len(live))
+    strands = np.where(st["minus"], "-", "+").tolist()
+    cns = st["cn"][kept].tolist()
+    scs = [None if x != x else x for x in st["sc"][kept].tolist()]
+    sls = st["ntr"][kept].tolist()
     # read weights (call_locus.py:1254-1259, output.read_weights) for all loci at once: the lengths of ALL records fetched
     # for a locus, sorted inside the locus; L = mean length of those that could contain flank + tract + flank
     big = np.int64(1) << 40
-    lens_all = bam.l_seq[rec].astype(np.int64)
+    lens_all = st["lens_all"]
     order = np.lexsort((lens_all, item_locus))
     key = item_locus[order] * big + lens_all[order]
     csum = np.concatenate(([0], np.cumsum(lens_all[order])))
     loc_end = np.cumsum(counts)                                   # end of each locus' run in `order`
-    tlwf = (batch.nfl[kept].astype(np.int64) + batch.ntr[kept] + batch.nfr[kept])
+    tlwf = (st["nfl"][kept].astype(np.int64) + st["ntr"][kept] + st["nfr"][kept])
     part = np.searchsorted(key, read_locus[kept] * big + tlwf, side="left")
     e_ = loc_end[read_locus[kept]]
     L = (csum[e_] - csum[part]) / np.maximum(e_ - part, 1)
