@@ -22,7 +22,7 @@ def main(argv=None) -> int:
     c.add_argument("--front-end", choices=("auto", "device", "host"), default="auto",
                    help="where the alignment file is inflated, scanned and cut: on the GPU (whole below 24 GB: about six times the "
                         "file in device memory; larger files with a .bai in spans) or on the host cores, block by block through "
-                        "the .bai; auto = device in a single-process run")
+                        "the .bai; auto = device (a file of 24 GB or more needs its .bai for that)")
     c.add_argument("--span-mb", type=int, default=4096,
                    help="device front end, files of 24 GB and more: compressed megabytes of the file that go through device memory at a time")
     c.add_argument("--respect-ref", action="store_true")

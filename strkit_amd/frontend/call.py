@@ -236,7 +236,8 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
     whole when it is below 24 GB (its decompressed form, about six times the file, stays in device memory next to the
     workspace), else, with a .bai, in spans of at most `span_bytes` compressed bytes that follow the catalog; "host" =
     block-wise through the .bai on the host cores (IndexedBam) or, without an index, the whole stream (NativeBam); "auto" =
-    "device" in a single-process run (a file of 24 GB or more needs its index for that), else "host"."""
+    "device" (a file of 24 GB or more needs its index for that), else "host".  Under torch.distributed every rank opens the
+    file on its own GPU and calls its share of the blocks."""
     t_open = time.perf_counter()
     own_reader = isinstance(bam, str)
     if isinstance(bam, str):
@@ -245,7 +246,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
             raise ValueError("front_end must be auto, device or host")
         has_index = os.path.exists(bam + ".bai") or os.path.exists(os.path.splitext(bam)[0] + ".bai")
         small = os.path.getsize(bam) < (24 << 30)               # decompressed (about six times that) it fits in HBM
-        use_device = front_end == "device" or (front_end == "auto" and (small or has_index) and not _distributed())
+        use_device = front_end == "device" or (front_end == "auto" and (small or has_index))
         # (the device of the rank, as _lib.default_context picks it: one process per GPU)
         dev = int(os.environ.get("STRKIT_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         if use_device:                                            # a larger file goes through HBM span by span (needs the index)

@@ -407,3 +407,42 @@ def test_streamed_device_front_end_gives_the_resident_report(gpu_ctx, tmp_path):
         assert db.open_stage_s["spans"] == 2
     finally:
         db.close()
+
+
+def _two_rank_call_worker(rank, world, port, paths, q):
+    os.environ["STRKIT_AMD_DEVICE"] = "0"            # both ranks share the one GPU of the test box
+    import torch.distributed as dist
+    from strkit_amd.frontend import call_sample
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rep = call_sample(paths["bam"], paths["ref"], paths["loci"])
+    q.put((rank, rep["results"], rep["stage_times"].get("front_end"), rep["catalog"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_from_files_give_the_single_process_report(gpu_ctx, tmp_path):
+    """`call_sample` under torch.distributed (world size 2, gloo, both ranks on this box's GPU): every rank opens the file with
+    the device front end, calls its share of the locus blocks, and all ranks end with the report of a single process — the
+    fixed-size record gather of call_blocks_sharded on real rows."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from strkit_amd.frontend.synth_large import make_dataset_large
+    t = make_dataset_large(str(tmp_path), n_loci=420, depth=7, read_len=3000, seed=31, spacing=9000, procs=4)
+    want = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"])
+    assert want["stage_times"]["front_end"] == "device" and len(want["results"]) == 420
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_call_worker, args=(r, 2, port, t["paths"], q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rows, fe, cat in got:
+        assert fe == "device" and cat == want["catalog"]
+        assert rows == want["results"], rank
