@@ -297,7 +297,8 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
         if isinstance(opened[0], BaseException):
             raise opened[0]
         bam, t_open = opened[0], opened[1]
-    n_catalog = sum(1 for _ in parse_loci_bed(loci_file))
+    with open(loci_file) as fh:                  # the catalog's size (the lines parse_loci_bed yields), without parsing them again
+        n_catalog = sum(1 for raw in fh if raw.strip() and not raw.lstrip().startswith("#"))
     n_loaded = sum(len(b) for b in blocks)
     if n_loaded < n_catalog:
         print(f"strkit_amd: {n_catalog - n_loaded} of {n_catalog} catalog loci lie on contigs that the alignment file or "
