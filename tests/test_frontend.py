@@ -519,6 +519,21 @@ def test_device_inflater_code_on_the_host_equals_zlib(tmp_path):
     assert L.strk_bgzf_inflate_sw(bad.ctypes.data, bad.size, b.ctypes.data, b.size) < 0 and b"BGZF" in L.strk_last_error()
 
 
+def test_inflater_code_is_clean_under_the_sanitizers(tmp_path):
+    """tools/inflate_asan.sh: strk_inflate.h compiled for the host with AddressSanitizer + UBSan inflates every block of a
+    synthetic BAM and of streams for every copy path into heap buffers of exactly the block's size (the decoder stores whole
+    words past the end of a match and reads its input up to 16 bytes ahead: never outside the block / the padded payload)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(HERE)
+    r = subprocess.run(["bash", "tools/inflate_asan.sh"], cwd=root, env={**os.environ, "TMPDIR": str(tmp_path)}, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "sanitize" in r.stderr and "cannot find" in r.stderr:
+        pytest.skip("the sanitizer run-time libraries are not installed")
+    assert r.returncode == 0 and "clean" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_indexed_bam_slots_reuse_their_buffers(tmp_path):
     """IndexedBam.region(slot=k): the same records as without a slot, in a buffer that the next region of the slot takes over."""
     from strkit_amd.frontend import IndexedBam
