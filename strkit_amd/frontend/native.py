@@ -580,11 +580,19 @@ class DeviceBam(_Records):
         n = int(idx.size)
         if n == 0:
             return []
-        off = np.concatenate(([0], np.cumsum(np.maximum(self.l_name[idx] - 1, 0)))).astype(np.int64)
+        ln = self.l_name[idx]
+        with_nul = bool((ln >= 1).all())         # l_name counts the terminating NUL: copied along, the text splits at it
+        off = np.concatenate(([0], np.cumsum(ln if with_nul else np.maximum(ln - 1, 0)))).astype(np.int64)
         rec_off = np.ascontiguousarray(self.rec_off[idx], np.int64)
         buf = np.empty(max(int(off[-1]), 1), np.uint8)
         _lib.check(_lib.load().strk_dbam_names(self._h, n, rec_off.ctypes.data, off.ctypes.data, buf.ctypes.data))
         text = buf[:int(off[-1])].tobytes().decode()
+        if with_nul:
+            names = text.split("\0")
+            if len(names) == n + 1 and not names[-1]:
+                return names[:n]
+            o = off.tolist()                     # (a NUL inside a name: cut by the offsets)
+            return [text[o[i]:o[i + 1] - 1] for i in range(n)]
         o = off.tolist()
         return [text[o[i]:o[i + 1]] for i in range(n)]
 
