@@ -164,7 +164,7 @@ def get_read_coords_from_cigar(left_flank_coord: int, left_coord: int, right_coo
     if n == 0:
         return out
     out.full_left_flank = ix.first_ref() <= left_flank_coord
-    out.full_right_flank = ix.last_ref() >= right_flank_coord - 1
+    out.full_right_flank = ix.last_ref() >= right_flank_coord      # call_locus.py:907-909, as above
     if not (out.full_left_flank and out.full_right_flank):
         if not allow_only_one_full_flank or not (out.full_left_flank or out.full_right_flank):
             return out

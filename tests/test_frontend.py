@@ -9,7 +9,7 @@ import pytest
 from strkit_amd.frontend import (Fasta, Locus, LocusValidationError, find_pair_by_ref_pos, get_aligned_pairs,
                                  get_read_coords_from_matched_pairs, get_sequence_data_for_locus, load_loci,
                                  parse_last_column, read_bam, valid_motif, validate_locus, write_bam)
-from strkit_amd.frontend.extract import LowMeanBaseQual
+from strkit_amd.frontend.extract import LowMeanBaseQual, get_read_coords_from_cigar
 from strkit_amd.frontend.synth_dataset import make_dataset
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -120,6 +120,37 @@ def test_read_coordinates_put_boundary_insertions_into_the_tract():
     Seg.query_qualities[10:22] = 5
     with pytest.raises(LowMeanBaseQual):
         get_sequence_data_for_locus(Seg, c, 10)
+
+
+def test_right_flank_boundary_agrees_in_all_four_implementations():
+    """call_locus.py:907-909 skips a read when right_flank_coord >= segment.end: with segment.end == right_flank_coord the
+    read is dropped, with segment.end == right_flank_coord + 1 it is kept — in the pair-list walk, the run index
+    (extract.py), the host C++ run index (strk_frontend.h) and the one-pass walk the device runs (strk_bamrec.h)."""
+    import ctypes as C
+    from strkit_amd import _lib
+    L = _lib.load()
+
+    class Seg:
+        start = 100
+        cigar = np.array([(30 << 4) | 0, (3 << 4) | 1, (20 << 4) | 0], np.uint32)      # 30M 3I 20M: reference [100, 150)
+        query_sequence = "A" * 53
+        query_qualities = np.full(53, 30)
+    seg_end = 150
+    q, r = get_aligned_pairs(Seg)
+    for rfc, spans in ((seg_end - 1, True), (seg_end, False), (seg_end + 1, False)):
+        args = (100, 110, 130, rfc)
+        a = get_read_coords_from_matched_pairs(*args, q, r)
+        b = get_read_coords_from_cigar(*args, Seg)
+        assert a.full_right_flank == b.full_right_flank == spans, (rfc, a, b)
+        assert a.is_incomplete() == b.is_incomplete() == (not spans)
+        assert (a.left_flank_start, a.left_flank_end, a.right_flank_start, a.right_flank_end) == \
+               (b.left_flank_start, b.left_flank_end, b.right_flank_start, b.right_flank_end)
+        c = np.array(args, np.int64)
+        o1, o2 = np.zeros(4, np.int64), np.zeros(4, np.int64)
+        rc = L.strk_read_coords_both(Seg.cigar.ctypes.data, len(Seg.cigar), Seg.start, c.ctypes.data, o1.ctypes.data, o2.ctypes.data)
+        assert rc == (3 if spans else 0), (rfc, rc)
+        if spans:
+            assert o1.tolist() == o2.tolist() == [a.left_flank_start, a.left_flank_end, a.right_flank_start, a.right_flank_end]
 
 
 def test_synthetic_dataset_extraction_recovers_the_alleles(tmp_path):
