@@ -45,8 +45,14 @@ N_SIMD = 256 * 4
 # (half rate: 16 lanes per clock); only plain v_add_u32 / v_add_f32 approach the SIMD-32 rate (2.3-2.6 cycles).
 VALU_CYCLES_PER_INST = 4.2
 DP_INSTS_PER_CELL_FLOOR = 2.25      # v_add_u32_sdwa + v_max3_i32 per cell + one v_perm_b32 per four cells
-PROFILE_TAG = "r02"                 # profiles/<tag>_pmc_summary.json holds the PMC passes of this same command
+PROFILE_TAG = "r03"                 # profiles/<tag>[_cfgN]_pmc_summary.json: the PMC passes of this same command (config N)
 UNIT_LOCI = 1000                    # one instance of a BASELINE config 2 / 3 batch
+# the five DP kernels of a call: (name, strk_stats field with its HIP-event duration)
+DP_KERNELS = (("k_dp_band", "band_kernel_ms"), ("k_dp_band_wide", "band_wide_kernel_ms"), ("k_dp_all", "dp_kernel_ms"),
+              ("k_dp_long", "long_kernel_ms"), ("k_dp_generic", "generic_kernel_ms"))
+SUB_CONFIGS = {3: (10000, "cfg3 shape: 10 000 loci x 20 ONT-error reads, motif 2-20 bp"),
+               4: (21250, "cfg4 shape, one GPU's eighth of the whole-genome catalog: 21 250 loci x 30 HiFi reads, 70 % motifs 1-6 bp / 30 % 7-20 bp"),
+               5: (250, "cfg5 shape, expansion stress: 250 loci x 40 reads, motif 1-6 bp, 50-2 000 copies")}
 
 
 def _gen_worker(args):
@@ -112,14 +118,61 @@ def cpu_baseline(cfg: int, sample_loci: int, pool, cores: int) -> dict:
             "reads_per_s_per_core": best["reads_per_s_per_core"], "gcups": best["gcups"], "scalar": out["scalar"], "simd": out.get("simd")}
 
 
-def pmc_summary(kernel: str) -> dict | None:
-    """Per-launch PMC readings of `kernel` from the committed rocprofv3 passes of this same command
+def pmc_summary(kernel: str, cfg: int = 2) -> dict | None:
+    """Per-launch PMC readings of `kernel` from the committed rocprofv3 passes of this same command on config `cfg`
     (profiles/README.md; separate --pmc passes, FETCH_SIZE / WRITE_SIZE in KiB)."""
+    name = f"{PROFILE_TAG}_pmc_summary.json" if cfg == 2 else f"{PROFILE_TAG}_cfg{cfg}_pmc_summary.json"
     try:
-        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             return json.load(f)[kernel]
     except Exception:  # noqa: BLE001
         return None
+
+
+def kernel_bytes(acc: dict) -> dict:
+    """Algorithmic bytes ((|window| + 16) per read) of the reads each DP kernel was handed."""
+    return {"k_dp_band": acc["band_bytes"] - acc["wide_bytes"], "k_dp_band_wide": acc["wide_bytes"],
+            "k_dp_all": acc["exact_bytes"] - acc["long_bytes"], "k_dp_long": acc["long_bytes"], "k_dp_generic": 0}
+
+
+def roofline_block(cfg: int, acc_timed: dict, iso: dict | None, n_timed: int, plain: bool) -> dict:
+    """`roofline` of the dominant kernel.  iso = per-kernel durations of one call at a time (un-overlapped), or None;
+    acc_timed = the same sums over the timed region, where calls_in_flight launches share the device."""
+    n = max(1, n_timed)
+    src = {k: iso[k] for k, _ in DP_KERNELS} if iso else {k: acc_timed[f] / n for k, f in DP_KERNELS}
+    kname = max(src, key=lambda k: src[k])
+    k_ms = max(src[kname], 1e-9)
+    alg = (iso["bytes"] if iso else {k: v / n for k, v in kernel_bytes(acc_timed).items()})[kname]
+    over_ms = acc_timed[dict(DP_KERNELS)[kname]] / n
+    roof = {"bound": "hbm", "achieved": alg / (k_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg / (k_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "strk::" + kname, "kernel_ms": k_ms, "kernel_ms_is": "un-overlapped (one call at a time)" if iso else "overlapped",
+            "kernel_ms_overlapped": over_ms, "algorithmic_bytes_per_launch": alg,
+            "dp_kernels_ms": {k: src[k] for k, _ in DP_KERNELS},
+            "note": "integer max-plus DP: what binds is VALU issue, not HBM (valu_* keys); achieved / frac divide the kernel's "
+                    "algorithmic bytes ((|window| + 16) per read it scored) by its HIP-event duration with ONE call on the device; "
+                    "kernel_ms_overlapped is the same kernel's event duration inside the timed region, where calls_in_flight "
+                    "launches share the CUs (not a throughput denominator)"}
+    pmc = pmc_summary(kname, cfg) if plain else None
+    if pmc:
+        roof["traffic"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        if "SQ_INSTS_VALU" in pmc:
+            clock_ghz = pmc.get("clock_ghz", 2.3)
+            floor_ms = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / N_SIMD / (clock_ghz * 1e9) * 1e3
+            cells_launch = (iso["cells"] if iso else acc_timed["cells"] / n)
+            roof.update({"valu_from_profile": f"profiles/{PROFILE_TAG}{'' if cfg == 2 else f'_cfg{cfg}'}_pmc_summary.json",
+                         "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES_PER_INST,
+                         "valu_clock_ghz": clock_ghz, "floor_ms": floor_ms,
+                         "profile_kernel_ms": pmc.get("unoverlapped_avg_us", 0.0) / 1e3,
+                         "frac_valu": floor_ms / k_ms,
+                         "insts_per_cell": pmc["SQ_INSTS_VALU"] * 64.0 / max(cells_launch, 1.0),
+                         "insts_per_cell_floor": DP_INSTS_PER_CELL_FLOOR,
+                         "frac_of_cell_floor": (cells_launch / 64.0 * DP_INSTS_PER_CELL_FLOOR * VALU_CYCLES_PER_INST / N_SIMD
+                                                / (clock_ghz * 1e9) * 1e3) / k_ms,
+                         "valu_note": "instruction counts come from the committed rocprofv3 PMC pass of this command (a live run cannot "
+                                      "count instructions); cells and kernel_ms are this run's: profile_kernel_ms far from kernel_ms "
+                                      "means the profile is stale"})
+    return roof
 
 
 def run_e2e(data: dict) -> dict:
@@ -157,11 +210,13 @@ def run_e2e(data: dict) -> dict:
                                                      / max(calling + st.get("open_s", 0.0), 1e-9)) if "front_end_device_s" in st else None,
                 "reads_with_true_allele_cn": n_true}, rep["results"]
 
-    # the device front end twice, the faster run reported (both walls listed): opening the file depends on where the box has
-    # the file's pages and the process's pinned buffers (open_stage_s says where a slow run lost its time)
+    # both front ends by the same protocol: two runs each, the FIRST one reported, both walls listed (opening the file depends
+    # on where the box has the file's pages and the process's pinned buffers: open_stage_s says where a run lost its time)
     runs = [one("device") for _ in range(2)]
-    dev, rows_dev = min(runs, key=lambda r: r[0]["wall_s"])
-    host, rows_host = one("host")
+    dev, rows_dev = runs[0]
+    hruns = [one("host") for _ in range(2)]
+    host, rows_host = hruns[0]
+    host["wall_s_runs"] = [r[0]["wall_s"] for r in hruns]
     out = dict(dev)
     out["wall_s_runs"] = [r[0]["wall_s"] for r in runs]
     out.update({"read_len": int(data.get("read_len", 0)) or None, "bam_mb": os.path.getsize(paths["bam"]) >> 20,
@@ -173,6 +228,11 @@ def run_e2e(data: dict) -> dict:
                         "the caller waited for it"})
     shutil.rmtree(data["dir"], ignore_errors=True)
     return out
+
+
+def progress(msg: str) -> None:
+    """Stage marker on stderr (stdout carries the one JSON line only)."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main() -> None:
@@ -194,6 +254,7 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip the pipeline-1 and host-buffer (PCIe-inclusive) sub-results")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (self-test)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end sub-result (BAM + FASTA + BED -> per-read copy numbers)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` sub-results (BASELINE configs 3, 4-shard, 5 timed on this GPU)")
     ap.add_argument("--e2e-loci", type=int, default=10000)
     ap.add_argument("--e2e-depth", type=int, default=30)
     ap.add_argument("--e2e-read-len", type=int, default=15000)
@@ -217,11 +278,17 @@ def main() -> None:
         if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
             import oracle
             oracle.build()
+            progress("cpu baseline")
             cpu = cpu_baseline(a.config, a.cpu_sample_loci, pool, cores)
+        progress("generating batches")
         if a.strong:
             catalog = make_batches(a.config, n_loci, 1, 0, pool)[0]      # the same catalog on every rank
         else:
             batches = make_batches(a.config, n_loci, max(1, a.batches), rank, pool)
+        sub_batches = {}
+        if rank == 0 and a.gpus == 1 and not a.no_extras and not a.no_configs and not a.strong and a.config == 2 and a.loci is None:
+            for c, (nl, _) in SUB_CONFIGS.items():     # the other single-GPU configurations of BASELINE.json, two batches each
+                sub_batches[c] = make_batches(c, nl, 2, 7, pool)
     e2e_data = None
     if rank == 0 and a.gpus == 1 and not a.no_e2e and not a.strong:
         # files for the end-to-end sub-result: north_star's "10 000 loci x 30x HiFi reads genotyped end-to-end", ~15 kb reads
@@ -303,8 +370,23 @@ def main() -> None:
     def out_of(i):
         return step_rows(stage[(i // G) % 2], i % G)
 
-    acc = dict(dp_ms=0.0, band_ms=0.0, all_ms=0.0, misses=0, fallback=0, dedup=0, band=0, band_fb=0, n=0, reads=0, loci=0,
-               band_bytes=0, exact_bytes=0, cells=0, windows=set())
+    def new_acc():
+        return dict(dp_kernel_ms=0.0, band_kernel_ms=0.0, band_wide_kernel_ms=0.0, long_kernel_ms=0.0, generic_kernel_ms=0.0,
+                    head_ms=0.0, replay_ms=0.0, all_ms=0.0, misses=0, fallback=0, dedup=0, band=0, band_fb=0, n=0, reads=0, loci=0,
+                    band_bytes=0, exact_bytes=0, wide_bytes=0, long_bytes=0, cells=0, windows=set())
+
+    def add_stats(ac, st_, n_reads, n_loci_):
+        for _k, f in DP_KERNELS:
+            ac[f] += getattr(st_, f)
+        ac["head_ms"] += st_.head_ms; ac["replay_ms"] += st_.replay_ms; ac["all_ms"] += st_.kernel_ms
+        ac["band"] += st_.n_band_reads; ac["band_fb"] += st_.n_band_fallback
+        ac["misses"] += st_.n_miss_reads; ac["fallback"] += st_.n_fallback; ac["dedup"] += st_.n_dedup_reads
+        ac["band_bytes"] += st_.band_bytes; ac["exact_bytes"] += st_.exact_bytes
+        ac["wide_bytes"] += st_.wide_bytes; ac["long_bytes"] += st_.long_bytes; ac["cells"] += st_.dp_cells
+        ac["windows"].add(int(st_.window_used))
+        ac["n"] += 1; ac["reads"] += n_reads; ac["loci"] += n_loci_
+
+    acc = new_acc()
 
     def submit(i):
         k = i % D
@@ -318,13 +400,7 @@ def main() -> None:
         k = i % D
         _lib.check(L.strk_finish(ctxs[k].handle, C.byref(st)))
         if timed:
-            acc["dp_ms"] += st.dp_kernel_ms; acc["band_ms"] += st.band_kernel_ms; acc["all_ms"] += st.kernel_ms
-            acc["band"] += st.n_band_reads; acc["band_fb"] += st.n_band_fallback
-            acc["misses"] += st.n_miss_reads; acc["fallback"] += st.n_fallback; acc["dedup"] += st.n_dedup_reads
-            acc["band_bytes"] += st.band_bytes; acc["exact_bytes"] += st.exact_bytes; acc["cells"] += st.dp_cells
-            acc["windows"].add(int(st.window_used))
-            acc["n"] += 1
-            acc["reads"] += batches[batch_of(i)].n_reads; acc["loci"] += batches[batch_of(i)].n_loci
+            add_stats(acc, st, batches[batch_of(i)].n_reads, batches[batch_of(i)].n_loci)
         if use_dist and (i + 1) % G == 0:  # a round is complete: collect it from every shard
             dist.all_gather_into_tensor(gathered, stage[(i // G) % 2])
 
@@ -350,6 +426,7 @@ def main() -> None:
     # workspace and tries the band on a sample of the reads, and the library settles the default candidate window after
     # eight calls without a miss -- none of which belongs to a steady-state step.
     prime = max(3 * D, 12)
+    progress("priming + warm-up + timed region")
     run(prime, False)
     flush(prime)
     fence()
@@ -374,43 +451,60 @@ def main() -> None:
         reads_all, loci_all = acc["reads"], acc["loci"]
 
     # ---- sub-results outside the timed region (rank 0 of a one-GPU run) -------------------------------------------
-    extras = {}
-    if rank == 0 and world == 1 and not a.no_extras:
-        # (a) one call at a time on one context: no overlap between calls; its per-kernel durations are un-overlapped
-        n1 = max(4, min(a.steps, 16))
-        iso = dict(dp=0.0, band=0.0, all=0.0)
+    def one_at_a_time(res_list, blist, n_calls, out_rows):
+        """n_calls calls, one at a time on context 0: (reads/s, ms per call, per-kernel un-overlapped durations + bytes + cells)."""
+        ac = new_acc()
         fence()
         t1 = time.perf_counter()
-        r1 = 0
-        for i in range(n1):
-            o = out_of(i)
-            _lib.check(L.strk_submit_loci_device(ctxs[0].handle, C.byref(res_b[i % NB][1]), C.byref(p), o[1].data_ptr(), o[2].data_ptr(),
-                                                 o[3].data_ptr(), o[4].data_ptr(), C.c_void_p(streams[0].cuda_stream)))
+        for i in range(n_calls):
+            _lib.check(L.strk_submit_loci_device(ctxs[0].handle, C.byref(res_list[i % len(res_list)][1]), C.byref(p), out_rows[1].data_ptr(),
+                                                 out_rows[2].data_ptr(), out_rows[3].data_ptr(), out_rows[4].data_ptr(),
+                                                 C.c_void_p(streams[0].cuda_stream)))
             _lib.check(L.strk_finish(ctxs[0].handle, C.byref(st)))
-            iso["dp"] += st.dp_kernel_ms / n1; iso["band"] += st.band_kernel_ms / n1; iso["all"] += st.kernel_ms / n1
-            r1 += batches[i % NB].n_reads
+            add_stats(ac, st, blist[i % len(blist)].n_reads, blist[i % len(blist)].n_loci)
         fence()
         e1 = time.perf_counter() - t1
-        extras["pipeline1"] = {"value": r1 / e1, "unit": "reads/s", "ms_per_step": e1 / n1 * 1e3, "steps": n1,
-                               "k_dp_band_ms": iso["band"], "k_dp_all_ms": iso["dp"], "device_ms": iso["all"],
+        iso_ = {k: ac[f] / n_calls for k, f in DP_KERNELS}
+        iso_["bytes"] = {k: v / n_calls for k, v in kernel_bytes(ac).items()}
+        iso_["cells"] = ac["cells"] / n_calls
+        iso_["head_ms"] = ac["head_ms"] / n_calls; iso_["replay_ms"] = ac["replay_ms"] / n_calls; iso_["device_ms"] = ac["all_ms"] / n_calls
+        return ac["reads"] / e1, e1 / n_calls * 1e3, iso_, ac
+
+    extras = {}
+    iso = None
+    if rank == 0 and world == 1 and not a.no_extras:
+        # (a) one call at a time on one context: no overlap between calls; its per-kernel durations are un-overlapped
+        progress("extras: one call at a time, host-buffer entry point")
+        n1 = max(4, min(a.steps, 16))
+        v1, ms1, iso, _ac1 = one_at_a_time(res_b, batches, n1, out_of(0))
+        extras["pipeline1"] = {"value": v1, "unit": "reads/s", "ms_per_step": ms1, "steps": n1,
+                               "k_dp_band_ms": iso["k_dp_band"], "k_dp_all_ms": iso["k_dp_all"], "k_dp_band_wide_ms": iso["k_dp_band_wide"],
+                               "k_dp_long_ms": iso["k_dp_long"], "head_ms": iso["head_ms"], "replay_ms": iso["replay_ms"],
+                               "device_ms": iso["device_ms"],
                                "note": "one call at a time: kernel durations are un-overlapped"}
-        # (b) the host-buffer entry point strk_count_loci: H2D of the batch + D2H of the results inside every step
-        nh = max(2, min(a.steps, 6))
+        # (b) the host-buffer entry point strk_count_loci: the batch starts in pageable host memory and the results end
+        # there, every step (sub-batches through three pinned slots: staging copy, H2D, kernels, D2H overlap)
+        nh = max(3, min(a.steps, 8))
         hb = [batch_struct(b) for b in batches[:min(NB, 3)]]
         outs = [np.zeros(n_reads_max, np.int32) for _ in range(4)]
-        for w in range(1 + nh):
-            if w == 1:
+        for w in range(2 + nh):
+            if w == 2:
                 t2 = time.perf_counter()
                 r2 = 0
             s, _keep = hb[w % len(hb)]
             _lib.check(L.strk_count_loci(ctxs[0].handle, C.byref(s), C.byref(p), *[o.ctypes.data for o in outs], C.byref(st)))
-            if w >= 1:
+            if w >= 2:
                 r2 += batches[w % len(hb)].n_reads
         e2 = time.perf_counter() - t2
+        bl_h = batches[(1 + nh) % len(hb)]
         extras["h2d_inclusive"] = {"value": r2 / e2, "unit": "reads/s", "ms_per_step": e2 / nh * 1e3, "steps": nh,
-                                   "note": "strk_count_loci with pageable host buffers in and out, one call at a time "
-                                           "(PCIe + staging copies inside the step); never the headline value"}
+                                   "sub_batches_per_step": int(st.n_dp_launches),
+                                   "bytes_h2d_per_step": int(bl_h.seqs.nbytes + bl_h.n_reads * 24),
+                                   "note": "strk_count_loci with pageable host buffers in and out, one call at a time; inside a call "
+                                           "sub-batches of whole loci travel through three pinned slots (strk_host_pipe.inc); never "
+                                           "the headline value"}
     if e2e_data is not None:
+        progress("extras: end to end from files")
         extras["e2e"] = run_e2e(e2e_data)
     fence()
 
@@ -428,53 +522,83 @@ def main() -> None:
                                             one[2].data_ptr(), one[3].data_ptr(), None, C.byref(st)))
         strong_check = "identical" if np.array_equal(table, one.cpu().numpy()) else "MISMATCH"
 
-    if rank == 0:
-        # sanity: the timed path's answers on the first loci of the last step agree with the oracle (checker only)
+    def parity_check(bl, got4):
+        """The device's answers (int32[4, >= n]: cn, score, n_iters, start) on the first loci of batch `bl` against the oracle
+        (checker only): up to eight loci, within ~1e9 scalar DP cells (long windows: config 5)."""
         import oracle
-        bl = batches[batch_of(last)]
-        n_chk, cells_chk = 0, 0          # up to eight loci, within ~1e9 scalar DP cells (long windows: config 5)
+        n_chk, cells_chk = 0, 0
         while n_chk < min(8, bl.n_loci) and cells_chk < 1e9:
             r0c, r1c = int(bl.read_off[n_chk]), int(bl.read_off[n_chk + 1])
             cells_chk += 9 * float(((bl.nfl[r0c:r1c] + bl.ntr[r0c:r1c] + bl.nfr[r0c:r1c]).astype(np.float64) ** 2).sum())
             n_chk += 1
         chk = bl.locus_slice(0, max(1, n_chk - (1 if cells_chk > 3e9 and n_chk > 1 else 0)))
-        got = out_last[1:5, :chk.n_reads].cpu().numpy()
-        parity = "ok"
+        verdict = "ok"
         for l in range(chk.n_loci):
             r0, r1_ = int(chk.read_off[l]), int(chk.read_off[l + 1])
             s0 = int(chk.seq_off[r0])
             o = oracle.count_locus(chk.seqs[s0:int(chk.seq_off[r1_])], chk.seq_off[r0:r1_ + 1] - s0, chk.nfl[r0:r1_],
                                    chk.ntr[r0:r1_], chk.nfr[r0:r1_], chk.est_cn[r0:r1_], chk.motif(l))
             for i, k in enumerate(("cn", "score", "n_iters", "start")):
-                if not np.array_equal(got[i, r0:r1_], o[k]):
-                    parity = f"MISMATCH locus {l} field {k}"
-        # the dominant kernel of the timed region: the banded kernel when most reads certify, else k_dp_all
+                if not np.array_equal(got4[i, r0:r1_], o[k]):
+                    verdict = f"MISMATCH locus {l} field {k}"
+        return verdict
+
+    # ---- the other single-GPU configurations of BASELINE.json, timed by this same run (rank 0 of a one-GPU default run) ----
+    configs_out = {}
+    for c in sorted(sub_batches):
+        progress(f"extras: config {c}")
+        bl_c = sub_batches[c]
+        res_c = [resident(b) for b in bl_c]
+        rows_c = max(b.n_reads for b in bl_c)
+        out_c = torch.zeros((D + 1, NF, rows_c), dtype=torch.int32, device=dev)
+        n_prime = 6 if c != 3 else 10          # band probation, window level, history-sized grids settle
+        for i in range(n_prime):
+            _lib.check(L.strk_count_loci_device(ctxs[i % D].handle, C.byref(res_c[i % 2][1]), C.byref(p), out_c[0, 1].data_ptr(),
+                                                out_c[0, 2].data_ptr(), out_c[0, 3].data_ptr(), out_c[0, 4].data_ptr(),
+                                                C.c_void_p(streams[i % D].cuda_stream), C.byref(st)))
+        k_steps = 6
+        ac_c = new_acc()
+        fence()
+        t_c = time.perf_counter()
+        for i in range(min(D, k_steps)):
+            _lib.check(L.strk_submit_loci_device(ctxs[i % D].handle, C.byref(res_c[i % 2][1]), C.byref(p), out_c[i % D, 1].data_ptr(),
+                                                 out_c[i % D, 2].data_ptr(), out_c[i % D, 3].data_ptr(), out_c[i % D, 4].data_ptr(),
+                                                 C.c_void_p(streams[i % D].cuda_stream)))
+        for i in range(k_steps):
+            _lib.check(L.strk_finish(ctxs[i % D].handle, C.byref(st)))
+            add_stats(ac_c, st, bl_c[i % 2].n_reads, bl_c[i % 2].n_loci)
+            j = i + D
+            if j < k_steps:
+                _lib.check(L.strk_submit_loci_device(ctxs[j % D].handle, C.byref(res_c[j % 2][1]), C.byref(p), out_c[j % D, 1].data_ptr(),
+                                                     out_c[j % D, 2].data_ptr(), out_c[j % D, 3].data_ptr(), out_c[j % D, 4].data_ptr(),
+                                                     C.c_void_p(streams[j % D].cuda_stream)))
+        fence()
+        el_c = time.perf_counter() - t_c
+        v1c, ms1c, iso_c, _ = one_at_a_time(res_c, bl_c, 2, out_c[D])
+        # (the one-at-a-time leg's last call ran batch 1 into out_c[D])
+        roof_c = roofline_block(c, ac_c, iso_c, ac_c["n"], True)
+        dp_ms_c = sum(iso_c[k] for k, _ in DP_KERNELS)
+        configs_out[f"cfg{c}"] = {
+            "workload": SUB_CONFIGS[c][1], "loci_per_step": bl_c[0].n_loci, "reads_per_step": bl_c[0].n_reads,
+            "value": ac_c["reads"] / el_c, "unit": "reads/s", "steps": k_steps, "ms_per_step": el_c / k_steps * 1e3, "calls_in_flight": D,
+            "one_call_at_a_time": {"value": v1c, "ms_per_step": ms1c},
+            "window": sorted(ac_c["windows"]), "band_reads_per_step": ac_c["band"] / ac_c["n"],
+            "band_fallback_per_step": ac_c["band_fb"] / ac_c["n"], "window_miss_reads_per_step": ac_c["misses"] / ac_c["n"],
+            "generic_kernel_items_per_step": ac_c["fallback"] / ac_c["n"], "dedup_reads_per_step": ac_c["dedup"] / ac_c["n"],
+            "gcups": iso_c["cells"] / max(dp_ms_c, 1e-9) / 1e6, "roofline": roof_c,
+            "parity_check": parity_check(bl_c[1], out_c[D, 1:5].cpu().numpy()),
+        }
+        del res_c, out_c
+    if configs_out:
+        extras["configs"] = configs_out
+
+    if rank == 0:
+        # sanity: the timed path's answers on the first loci of the last step agree with the oracle (checker only)
+        parity = parity_check(batches[batch_of(last)], out_last[1:5].cpu().numpy())
         n = max(1, acc["n"])
-        if acc["band_ms"] > acc["dp_ms"]:
-            kname, k_ms, alg_bytes = "k_dp_band", acc["band_ms"] / n, acc["band_bytes"] / n
-        else:
-            kname, k_ms, alg_bytes = "k_dp_all", acc["dp_ms"] / n, acc["exact_bytes"] / n
-        dp_s = max(k_ms, 1e-9) / 1e3
-        pmc = pmc_summary(kname) if (a.config == 2 and a.loci is None and not a.no_dedupe and not a.no_band and not a.strong) else None
-        roof = {"bound": "hbm", "achieved": alg_bytes / dp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": alg_bytes / dp_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if pmc else None,
-                "kernel": "strk::" + kname, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "integer max-plus DP: what binds is VALU issue, not HBM (valu_* keys); kernel_ms is the HIP-event duration "
-                        "of the kernel inside the timed region, where calls_in_flight launches share the device (pipeline1 holds "
-                        "the un-overlapped duration); algorithmic bytes = (|window| + 16) per read this kernel scored"}
-        if pmc and "SQ_INSTS_VALU" in pmc:
-            clock_ghz = pmc.get("clock_ghz", 2.3)
-            floor_ms = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / N_SIMD / (clock_ghz * 1e9) * 1e3
-            un_ms = extras.get("pipeline1", {}).get("k_dp_band_ms" if kname == "k_dp_band" else "k_dp_all_ms") or k_ms
-            cells_launch = pmc.get("cells_per_launch") or acc["cells"] / n
-            roof.update({"valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES_PER_INST,
-                         "valu_clock_ghz": clock_ghz, "floor_ms": floor_ms, "unoverlapped_kernel_ms": un_ms,
-                         "frac_valu": floor_ms / un_ms,
-                         "insts_per_cell": pmc["SQ_INSTS_VALU"] * 64.0 / cells_launch,
-                         "insts_per_cell_floor": DP_INSTS_PER_CELL_FLOOR,
-                         "frac_of_cell_floor": (cells_launch / 64.0 * DP_INSTS_PER_CELL_FLOOR * VALU_CYCLES_PER_INST / N_SIMD
-                                                / (clock_ghz * 1e9) * 1e3) / un_ms})
+        plain = a.loci is None and not a.no_dedupe and not a.no_band and not a.strong and a.window == 0
+        roof = roofline_block(a.config, acc, iso, acc["n"], plain)
+        dp_ms_un = sum(iso[k] for k, _ in DP_KERNELS) if iso else None
         b0 = batches[0]
         wl = (f"cfg{a.config} shape" + (" (1000 loci x 30 HiFi reads, motif 3-6 bp, flank 70)" if a.config == 2 else "") +
               (f": ONE catalog of {catalog.n_loci} loci dealt to {world} rank(s) in blocks of <= 200 loci by estimated cells" if a.strong else
@@ -491,8 +615,9 @@ def main() -> None:
                        "calls_in_flight": D},
             "loci_per_s": loci_all / elapsed,
             "roofline": roof,
-            "valu": {"gcups": acc["cells"] / max(acc["dp_ms"] + acc["band_ms"], 1e-9) / 1e6, "cells_per_step": acc["cells"] / n,
-                     "unit": "G cell updates/s (cells the DP kernels executed / their summed HIP-event time)"},
+            "valu": {"gcups": (iso["cells"] / max(dp_ms_un, 1e-9) / 1e6) if iso else None, "cells_per_step": acc["cells"] / n,
+                     "unit": "G cell updates/s: cells the DP kernels executed per call / the summed un-overlapped durations of all five "
+                             "DP kernels (one call at a time)"},
             "device_ms_per_step": acc["all_ms"] / n,
             "band_reads_per_step": acc["band"] / n, "band_fallback_per_step": acc["band_fb"] / n, "band": not a.no_band,
             "window_miss_reads_per_step": acc["misses"] / n, "generic_kernel_items_per_step": acc["fallback"] / n,

@@ -58,6 +58,7 @@ extern "C" {
 
 #define STRK_TIE_FIRST 0 /* Python max(): first maximal element (repeats.py:135,154) */
 #define STRK_TIE_LAST 1
+#define STRK_NARROW_NONE 0
 
 typedef struct strk_ctx strk_ctx;
 
@@ -84,7 +85,13 @@ typedef struct strk_params {
     int32_t no_band;            /* 0 (default): reads whose window is much wider than the band the search can
                                    reach are scored by the banded kernel first and re-scored exactly only when
                                    the exactness certificate fails; 1: exact kernels only */
-    int32_t reserved;
+    int32_t narrowing;          /* schedule by which local_search_range / step_size shrink inside one search
+                                   (repeat_count_params.py:14: "can be narrowed within the get_repeat_count fn").
+                                   STRK_NARROW_NONE (0): fixed for the whole search, as get_ref_repeat_count does
+                                   (repeats.py:100-151) — the only schedule the tree states.  Any other value is rejected
+                                   with STRK_E_INVALID: the field exists so that a sweep (tools/compare_strkit_json.py) can
+                                   name the switch once the Rust function's schedule is known; search_replay() is the one
+                                   place it would change. */
 } strk_params;
 
 /* CSR-packed batch of loci.  Read r owns seqs[seq_off[r] .. seq_off[r+1]) laid out fl|tr|fr;
@@ -120,14 +127,25 @@ typedef struct strk_stats {
     float band_kernel_ms;  /* HIP-event time of the banded kernel (k_dp_band) of this call */
     int32_t window_used;   /* half-width of the speculative candidate window this call ran with (params.window, or the
                               level the library's default has adapted to) */
-    int64_t band_bytes;    /* algorithmic bytes (|window| + 16 per read) of the reads k_plan routed to k_dp_band */
+    int64_t band_bytes;    /* algorithmic bytes (|window| + 16 per read) of the reads k_plan routed to k_dp_band / k_dp_band_wide */
     int64_t exact_bytes;   /* ... and to the exact kernels (k_dp_all / k_dp_long / generic) */
+    float band_wide_kernel_ms; /* HIP-event time of k_dp_band_wide (band classes 2, 3: long windows) */
+    float long_kernel_ms;      /* ... of k_dp_long (column-tiled exact kernel) */
+    float generic_kernel_ms;   /* ... of k_dp_generic */
+    float head_ms;             /* ... of what precedes the DP kernels (k_hash, k_plan) */
+    float replay_ms;           /* ... of k_replay */
+    int32_t n_long_reads;      /* reads scored by k_dp_long */
+    int64_t wide_bytes;        /* algorithmic bytes of the reads routed to k_dp_band_wide (part of band_bytes) */
+    int64_t long_bytes;        /* ... to k_dp_long (part of exact_bytes) */
 } strk_stats;
 
 int strk_init(int device, strk_ctx** out);
 void strk_destroy(strk_ctx* ctx);
 const char* strk_last_error(void);
 const char* strk_version(void);
+/* free / total memory of a device in bytes (hipMemGetInfo): how the file front end decides whether an alignment file's
+ * decompressed form stays resident or is streamed in spans. */
+int strk_device_mem(int device, int64_t* free_bytes, int64_t* total_bytes);
 
 /* Scalar drop-in for strkit_rust_ext.get_repeat_count (repeats.py:58-68).  Return contract
  * (repeats.py:55-56): ((out_cn, out_score), out_n_explored, out_cn - start_count). */
@@ -207,6 +225,20 @@ int strk_realign(strk_ctx* ctx, int32_t n_pairs, const uint8_t* s1, const int64_
                  const int64_t* s2_off, int32_t open, int32_t extend, int32_t gap_pref, int32_t* out_score,
                  int32_t* out_end_ref, int32_t* out_n_cigar, uint32_t* cigar, const int64_t* cigar_off,
                  strk_stats* stats);
+
+/* What parasail's fixed 16-bit kernel (sg_dx_trace_scan_16, strkit/call/realign.py:56) would have done with these pairs:
+ * strk_realign computes in 32 bits and never saturates, the reference's call can.  Per pair out_flags[p] =
+ *   STRK_I16_SCORE_SATURATES (2)  the final score itself exceeds what the 16-bit kernel can hold (> 32767 - 2, the matrix
+ *                                 maximum is kept as head-room): parasail would return a saturated result and
+ *                                 realign_read would compare garbage with its threshold (realign.py:65);
+ *   STRK_I16_CELL_MAY_SATURATE (1) the score fits, but an intermediate cell can reach the limit (2 * min(|s1|, |s2|) > 32765):
+ *                                 whether the reference's result is affected cannot be told from the score alone;
+ *   0                              no cell can reach the limit (every window of at most 16 382 bases).
+ * Pure host arithmetic on the lengths and on strk_realign's scores; no context. */
+#define STRK_I16_CELL_MAY_SATURATE 1
+#define STRK_I16_SCORE_SATURATES 2
+int strk_realign_i16_flags(int32_t n_pairs, const int64_t* s1_off, const int64_t* s2_off, const int32_t* scores,
+                           int32_t* out_flags);
 
 /* ---- host-side front end (CPU only; no context, thread-safe) ---------------------------------------------------
  * What the reference's Rust extension does before the counter runs: walk the alignment records

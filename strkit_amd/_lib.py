@@ -13,6 +13,8 @@ from . import _build
 
 STRK_SG_ALL = 15
 STRK_TIE_FIRST, STRK_TIE_LAST = 0, 1
+STRK_NARROW_NONE = 0
+STRK_I16_CELL_MAY_SATURATE, STRK_I16_SCORE_SATURATES = 1, 2
 STRK_E_EMPTY = -61
 
 _u8p = C.POINTER(C.c_uint8)
@@ -23,7 +25,7 @@ _i64p = C.POINTER(C.c_int64)
 class StrkParams(C.Structure):
     _fields_ = [("max_iters", C.c_int32), ("local_search_range", C.c_int32), ("step_size", C.c_int32),
                 ("tie_rule", C.c_int32), ("end_flags", C.c_int32), ("feedback", C.c_int32), ("window", C.c_int32),
-                ("no_dedupe", C.c_int32), ("no_band", C.c_int32), ("reserved", C.c_int32)]
+                ("no_dedupe", C.c_int32), ("no_band", C.c_int32), ("narrowing", C.c_int32)]
 
 
 class StrkBatch(C.Structure):
@@ -37,16 +39,18 @@ class StrkStats(C.Structure):
                 ("n_miss_rounds", C.c_int32), ("kernel_ms", C.c_float), ("dp_kernel_ms", C.c_float),
                 ("n_dp_launches", C.c_int32), ("n_dedup_reads", C.c_int32), ("n_band_reads", C.c_int32),
                 ("n_band_fallback", C.c_int32), ("band_kernel_ms", C.c_float), ("window_used", C.c_int32),
-                ("band_bytes", C.c_int64), ("exact_bytes", C.c_int64)]
+                ("band_bytes", C.c_int64), ("exact_bytes", C.c_int64), ("band_wide_kernel_ms", C.c_float),
+                ("long_kernel_ms", C.c_float), ("generic_kernel_ms", C.c_float), ("head_ms", C.c_float), ("replay_ms", C.c_float),
+                ("n_long_reads", C.c_int32), ("wide_bytes", C.c_int64), ("long_bytes", C.c_int64)]
 
     def as_dict(self) -> dict:
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 # Every symbol include/strkit_amd.h declares (tests check the .so exports exactly these).
-EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_repeat_count", "strk_count_loci",
+EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_device_mem", "strk_repeat_count", "strk_count_loci",
            "strk_count_loci_device", "strk_submit_loci_device", "strk_finish", "strk_score_table",
-           "strk_score_ref_table", "strk_ref_repeat_count", "strk_ref_repeat_count_batch", "strk_realign", "strk_bam_scan",
+           "strk_score_ref_table", "strk_ref_repeat_count", "strk_ref_repeat_count_batch", "strk_realign", "strk_realign_i16_flags", "strk_bam_scan",
            "strk_extract_reads", "strk_bgzf_inflate", "strk_bgzf_inflate_range", "strk_bam_names", "strk_bam_scan_piece",
            "strk_dbam_open", "strk_dbam_close", "strk_dbam_release_cache", "strk_dbam_inflate", "strk_dbam_inflate_file", "strk_dbam_inflate_file_range", "strk_dbam_file_ms", "strk_dbam_download", "strk_dbam_data", "strk_bgzf_inflate_sw",
            "strk_dbam_download_seqs", "strk_dbam_kernel_ms", "strk_dbam_voffsets", "strk_dbam_scan", "strk_dbam_extract", "strk_dbam_names", "strk_count_loci_dseqs", "strk_read_coords_both")
@@ -170,8 +174,19 @@ def load(build: bool = True):
         L.strk_realign.restype = C.c_int
         L.strk_realign.argtypes = ([C.c_void_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p] * 5
                                    + [C.POINTER(StrkStats)])
+        L.strk_device_mem.restype = C.c_int
+        L.strk_device_mem.argtypes = [C.c_int, _i64p, _i64p]
+        L.strk_realign_i16_flags.restype = C.c_int
+        L.strk_realign_i16_flags.argtypes = [C.c_int32] + [C.c_void_p] * 4
         _lib = L
         return L
+
+
+def device_mem(device: int = 0) -> tuple[int, int]:
+    """(free, total) bytes of a device's memory."""
+    f, t = C.c_int64(), C.c_int64()
+    check(load().strk_device_mem(int(device), C.byref(f), C.byref(t)))
+    return f.value, t.value
 
 
 def check(rc: int) -> None:

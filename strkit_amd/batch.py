@@ -19,13 +19,13 @@ __all__ = ["count_loci", "score_table", "score_ref_table", "make_params", "batch
 
 def make_params(rc_params: RepeatCountParams | None = None, feedback: bool = True, window: int = 0,
                 tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL,
-                dedupe: bool = True, band: bool = True) -> _lib.StrkParams:
+                dedupe: bool = True, band: bool = True, narrowing: int = _lib.STRK_NARROW_NONE) -> _lib.StrkParams:
     rc = rc_params or default_read_rc_params()
     if rc.method != "repalign":
         raise NotImplementedError("only rc_method='repalign' runs on the GPU backend")
     return _lib.StrkParams(max_iters=rc.max_iters, local_search_range=rc.initial_local_search_range,
                            step_size=rc.initial_step_size, tie_rule=tie_rule, end_flags=end_flags,
-                           feedback=int(feedback), window=window, no_dedupe=int(not dedupe), no_band=int(not band), reserved=0)
+                           feedback=int(feedback), window=window, no_dedupe=int(not dedupe), no_band=int(not band), narrowing=int(narrowing))
 
 
 def _ptr(a: np.ndarray) -> int:

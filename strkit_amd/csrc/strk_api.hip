@@ -45,6 +45,7 @@ extern "C" int strk_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8
 namespace {
 
 thread_local std::string g_err;
+struct HostPipe;   // strk_host_pipe.inc: the pinned-slot pipeline behind strk_count_loci
 
 // batched calls submitted and not yet finished, over all contexts of this process: a call that will share the
 // device with others takes half the CU slots, so that the tail of one call and the head of the next co-run
@@ -55,8 +56,10 @@ std::atomic<int> g_calls_in_flight{0};
 // Misses cost extra rounds on the host: a call with more than a handful (> 0.4 % of its loci) moves a level up at
 // once; eight (from the two widest levels: sixty-four) calls in a row with at most one miss per two thousand loci move
 // a level down.
-std::atomic<int> g_win_level{1};
-std::atomic<int> g_win_quiet{0};
+// One level per motif-length bucket (win_bucket): the estimate round(|tr| / |motif|) is off by the read's indel drift divided
+// by the motif length, so the reads of long motifs stay inside narrow windows that those of short ones leave.
+std::atomic<int> g_win_level[4] = {{1}, {1}, {1}, {1}};
+std::atomic<int> g_win_quiet[4] = {{0}, {0}, {0}, {0}};
 
 // CPUs this process may run on (a container's share, not the machine's core count)
 int host_cpus() {
@@ -86,12 +89,14 @@ int fail(int code, const char* fmt, ...) {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    int ensure(size_t bytes) {
+    // head_room: a quarter more than asked for, so that a buffer that grows call by call is not re-allocated every time;
+    // the two multi-gigabyte buffers of an alignment file (strk_dbam.inc) take exactly what they need
+    int ensure(size_t bytes, bool head_room = true) {
         if (bytes <= cap) return 0;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
+        size_t want = head_room ? bytes + bytes / 4 + 256 : bytes + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;
@@ -121,12 +126,15 @@ struct strk_ctx {
     // realignment (strk_realign)
     DevBuf rl_s1, rl_s2, rl_pairs, rl_trace, rl_edge, rl_out, rl_cigar, rl_queue;
     int32_t* h_counters = nullptr;  // pinned: counters + cells + scratch_used
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // call start, exact DP start/end, call end, band start/end
+    // a chain of events along one call: start | after k_hash + k_plan | after k_dp_band | after k_dp_band_wide | after
+    // k_dp_all / k_dp_ref | after k_dp_long | after k_dp_generic | end (after k_replay and the counters' copy)
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_ints = 0;
     int band_cooldown = 0;   // > 0: the band kernel is switched off for that many calls (too many certificates failed)
     int band_penalty = 32;   // length of the next cool-down (doubles while retries keep failing)
     bool band_probation = true;   // the band has not proved itself on this context's data yet: only a sample of the reads takes it
     bool p_window_auto = false;
+    int p_window_b[4] = {0, 0, 0, 0};   // the pending call's window per motif-length bucket (0: params.window for all)
     // work-queue lengths of the previous finished call (wave chunks), used to size the persistent grids of the
     // kernels that usually have little or nothing to do: an idle block still claims its 70-80 KB of LDS on a CU
     // and so delays the band blocks of the calls it overlaps with
@@ -139,6 +147,7 @@ struct strk_ctx {
     strk::KArgs p_args;
     strk::ReplayArgs p_replay;
     hipStream_t p_stream = nullptr;
+    HostPipe* pipe = nullptr;   // created by the first large strk_count_loci call of this context
 };
 
 namespace {
@@ -146,6 +155,7 @@ namespace {
 using namespace strk;
 
 constexpr int kDefaultWindow = 8;
+enum { kEvStart = 0, kEvHead, kEvBand, kEvWide, kEvExact, kEvLong, kEvGeneric, kEvEnd, kNumEvents };
 constexpr int kBandProbationReads = 2048;
 constexpr int kWindowLevels[4] = {6, 8, 11, 15};   // default half-widths of the candidate window, see g_win_level
 // Scratch pool (int32 units): kLongWaves slots of kLongSlotInts for k_dp_long (one per resident wave; a slot
@@ -157,7 +167,7 @@ constexpr size_t kLongSlotInts = (size_t)48 << 10;
 constexpr size_t kScratchInts = kLongWaves * kLongSlotInts + ((size_t)16 << 20);
 // device layout of the `counters` buffer: int32[kCntTotal] | pad | u64 cells | u64 scratch_used
 constexpr size_t kCellsOff = 64 * sizeof(int32_t);
-constexpr size_t kCountersBytes = kCellsOff + 4 * sizeof(unsigned long long);   // cells, scratch_used, band bytes, exact bytes
+constexpr size_t kCountersBytes = kCellsOff + 6 * sizeof(unsigned long long);   // cells, scratch_used, band / exact / wide-band / long-kernel bytes
 
 int check_params(const strk_params* p, strk_params* out) {
     if (!p) return fail(STRK_E_INVALID, "params is NULL");
@@ -168,6 +178,9 @@ int check_params(const strk_params* p, strk_params* out) {
         return fail(STRK_E_INVALID, "local_search_range must be >= 0 and step_size >= 1");
     if (out->tie_rule != STRK_TIE_FIRST && out->tie_rule != STRK_TIE_LAST) return fail(STRK_E_INVALID, "bad tie_rule");
     if (out->end_flags < 0 || out->end_flags > 15) return fail(STRK_E_INVALID, "bad end_flags");
+    if (out->narrowing != STRK_NARROW_NONE)
+        return fail(STRK_E_INVALID, "narrowing schedule %d is not implemented (only STRK_NARROW_NONE: the search parameters stay fixed, "
+                                    "as in get_ref_repeat_count)", out->narrowing);
     return 0;
 }
 
@@ -222,6 +235,7 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
     a.dbg = dbg;
     a.end_flags = end_flags;
     a.window = window;
+    for (int k = 0; k < 4; ++k) a.window_b[k] = c->p_window_b[k] > 0 ? c->p_window_b[k] : window;
     a.table_stride = table_stride;
     if (sp) {  // speculative search for start == est_cn inside the DP kernel
         a.spec = static_cast<int4*>(c->spec.p);
@@ -256,15 +270,19 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
         const int blocks = chunks == 0 ? 1 : (int)(scaled * 1.5 / 4.0) + 2;
         return std::max(1, std::min(full, blocks));
     };
-    if (a.band_mode && mode == 0 && !force_generic) {
+    if (time_dp) (void)hipEventRecord(c->ev[kEvHead], st);
+    const bool band = a.band_mode && mode == 0 && !force_generic;
+    int band_blocks = 1;
+    if (band) {
         // banded first pass: certified reads are done, the others are appended to the exact lists below
-        const int blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * eighths / 8, (a.list_stride + 3) / 4));
-        if (time_dp) (void)hipEventRecord(c->ev[4], st);
-        hipLaunchKernelGGL(k_dp_band, dim3(blocks), dim3(256), 0, st, a);
-        if (time_dp) (void)hipEventRecord(c->ev[5], st);
-        hipLaunchKernelGGL(k_dp_band_wide, dim3(predicted_blocks(c->hist_wide_chunks, blocks)), dim3(256), 0, st, a);   // long windows
+        band_blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * eighths / 8, (a.list_stride + 3) / 4));
+        hipLaunchKernelGGL(k_dp_band, dim3(band_blocks), dim3(256), 0, st, a);
     }
-    if (time_dp) (void)hipEventRecord(c->ev[1], st);
+    if (time_dp) (void)hipEventRecord(c->ev[kEvBand], st);
+    if (band) hipLaunchKernelGGL(k_dp_band_wide, dim3(predicted_blocks(c->hist_wide_chunks, band_blocks)), dim3(256), 0, st, a);   // long windows
+#ifndef STRK_FEW_EVENTS
+    if (time_dp) (void)hipEventRecord(c->ev[kEvWide], st);
+#endif
     if (!force_generic) {
         // persistent-style grid: every wave pulls chunks from the device-side queue until it is empty
         constexpr int kBlocksPerCU = std::max(1, std::min(8, (160 * 1024) / (4 * kWaveLdsBytes + kLdsSlack + 1024)));
@@ -273,10 +291,16 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
         if (a.ref_mode) hipLaunchKernelGGL(k_dp_ref, dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);
     }
-    if (time_dp) (void)hipEventRecord(c->ev[2], st);   // ev[1]..ev[2] brackets the dominant kernel alone
+    if (time_dp) (void)hipEventRecord(c->ev[kEvExact], st);
     if (!force_generic && !a.ref_mode)
         hipLaunchKernelGGL(k_dp_long, dim3(predicted_blocks(c->hist_long, kLongBlocks)), dim3(256), 0, st, a);
+#ifndef STRK_FEW_EVENTS
+    if (time_dp) (void)hipEventRecord(c->ev[kEvLong], st);
+#endif
     hipLaunchKernelGGL(k_dp_generic, dim3(256), dim3(256), 0, st, a);
+#ifndef STRK_FEW_EVENTS
+    if (time_dp) (void)hipEventRecord(c->ev[kEvGeneric], st);
+#endif
 }
 
 int check_error_bits(int bits) {
@@ -298,9 +322,14 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     if (!b || b->n_reads < 0 || b->n_loci < 0) return fail(STRK_E_INVALID, "bad batch");
     // default window: 8 sizes either side of the estimate to begin with, then what the sample needs (g_win_level)
     c->p_window_auto = params->window <= 0;
+    for (int k = 0; k < 4; ++k) c->p_window_b[k] = 0;
     if (c->p_window_auto) {
-        const int w = kWindowLevels[std::min(3, std::max(0, g_win_level.load(std::memory_order_relaxed)))];
-        p.window = std::max(w, std::min(kWindowLevels[3], p.local_search_range + p.step_size + 2));
+        p.window = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int w = kWindowLevels[std::min(3, std::max(0, g_win_level[k].load(std::memory_order_relaxed)))];
+            c->p_window_b[k] = std::max(w, std::min(kWindowLevels[3], p.local_search_range + p.step_size + 2));
+            p.window = std::max(p.window, c->p_window_b[k]);
+        }
     }
     c->p_batch = *b;
     c->p_params = p;
@@ -329,13 +358,13 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
         InFlight() { g_calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
         ~InFlight() { if (!keep) g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
     } in_flight;
-    HIP_TRY(hipEventRecord(c->ev[0], st));
+    HIP_TRY(hipEventRecord(c->ev[kEvStart], st));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
     if (a.rhash) hipLaunchKernelGGL(k_hash, dim3((b->n_reads + 31) / 32), dim3(256), 0, st, a);   // eight lanes per read
     enqueue_scoring(c, a, 0, nullptr, b->n_reads, 0, st, true);
     hipLaunchKernelGGL(k_replay, dim3(b->n_loci), dim3(64), 0, st, a, rp);
     HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(c->ev[3], st));
+    HIP_TRY(hipEventRecord(c->ev[kEvEnd], st));
     HIP_TRY(hipGetLastError());
     c->p_args = a;
     c->p_replay = rp;
@@ -353,18 +382,29 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
     const strk_batch* b = &c->p_batch;
     if (b->n_reads == 0 || b->n_loci == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventSynchronize(c->ev[3]));
+    HIP_TRY(hipEventSynchronize(c->ev[kEvEnd]));
     HIP_TRY(hipGetLastError());
     if (stats) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) stats->kernel_ms = ms;
-        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) stats->dp_kernel_ms = ms;
-        if (c->p_args.band_mode && hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) stats->band_kernel_ms = ms;
+        auto span = [&](int from, int to) {
+            float ms = 0.f;
+            return hipEventElapsedTime(&ms, c->ev[from], c->ev[to]) == hipSuccess ? ms : 0.f;
+        };
+        stats->kernel_ms = span(kEvStart, kEvEnd);
+        stats->head_ms = span(kEvStart, kEvHead);
+        stats->band_kernel_ms = span(kEvHead, kEvBand);
+        stats->band_wide_kernel_ms = span(kEvBand, kEvWide);
+        stats->dp_kernel_ms = span(kEvWide, kEvExact);
+        stats->long_kernel_ms = span(kEvExact, kEvLong);
+        stats->generic_kernel_ms = span(kEvLong, kEvGeneric);
+        stats->replay_ms = span(kEvGeneric, kEvEnd);
         {
             const unsigned long long* u = reinterpret_cast<const unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
             stats->band_bytes = (int64_t)u[2];
             stats->exact_bytes = (int64_t)u[3];
+            stats->wide_bytes = (int64_t)u[4];
+            stats->long_bytes = (int64_t)u[5];
         }
+        stats->n_long_reads = c->h_counters[kCntClass0 + kLongClass];
         stats->n_dp_launches = 2;
         stats->window_used = c->p_params.window;
         stats->n_fallback = c->h_counters[kCntClass0 + kGenericClass];
@@ -384,17 +424,20 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
     // (a call whose band certificates mostly failed reports those reads as misses too: not a window problem)
     const bool band_unhealthy = c->p_args.band_mode && n_band_reads >= 64 && 2 * c->h_counters[kCntBandFallback] > n_band_reads;
     if (c->p_window_auto && !band_unhealthy) {
-        const int level = g_win_level.load(std::memory_order_relaxed);
-        // a handful of misses costs less (one short extra round) than a wider window for every read does
-        const int n_miss = c->h_counters[kCntMiss];
-        if (n_miss > std::max(2, b->n_loci / 250)) {
-            if (level < 3) g_win_level.store(level + 1, std::memory_order_relaxed);
-            g_win_quiet.store(level == 0 ? -56 : 0, std::memory_order_relaxed);   // a failed narrow window is not retried soon
-        } else if (n_miss > b->n_loci / 2000) {   // more than one locus in two thousand: not a quiet call
-            g_win_quiet.store(0, std::memory_order_relaxed);
-        } else if (g_win_quiet.fetch_add(1, std::memory_order_relaxed) + 1 >= (level >= 2 ? 64 : 8) && level > 0) {
-            g_win_level.store(level - 1, std::memory_order_relaxed);
-            g_win_quiet.store(0, std::memory_order_relaxed);
+        for (int k = 0; k < 4; ++k) {
+            const int n_loci_k = c->h_counters[kCntLociB + k], n_miss = c->h_counters[kCntMissB + k];
+            if (n_loci_k == 0) continue;
+            const int level = g_win_level[k].load(std::memory_order_relaxed);
+            // a handful of misses costs less (one short extra round) than a wider window for every read does
+            if (n_miss > std::max(2, n_loci_k / 250)) {
+                if (level < 3) g_win_level[k].store(level + 1, std::memory_order_relaxed);
+                g_win_quiet[k].store(level == 0 ? -56 : 0, std::memory_order_relaxed);   // a failed narrow window is not retried soon
+            } else if (n_miss > std::max(1, n_loci_k / 1000)) {   // more than one locus in a thousand: not a quiet call
+                g_win_quiet[k].store(0, std::memory_order_relaxed);
+            } else if (g_win_quiet[k].fetch_add(1, std::memory_order_relaxed) + 1 >= (level >= 2 ? 64 : 8) && level > 0) {
+                g_win_level[k].store(level - 1, std::memory_order_relaxed);
+                g_win_quiet[k].store(0, std::memory_order_relaxed);
+            }
         }
     }
     {   // queue lengths of this call, for the grids of the next one (enqueue_scoring)
@@ -403,7 +446,7 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
             const int per = 64 / class_G(k);
             exact_chunks += (c->h_counters[kCntClass0 + k] + per - 1) / per;
         }
-        for (int k = 2; k < kNumBandClasses; ++k) {
+        for (int k = 2; k <= 3; ++k) {   // the classes of k_dp_band_wide
             const int per = 64 / band_class_G(k);
             wide_chunks += (c->h_counters[kCntClass0 + kBandClass0 + k] + per - 1) / per;
         }
@@ -496,6 +539,8 @@ int upload_batch(strk_ctx* c, const strk_batch* b, strk_batch* d, hipStream_t st
 }
 
 
+#include "strk_host_pipe.inc"
+
 // strk_score_table / strk_score_ref_table: explicit candidate windows per read, HOST buffers.
 // ref_mode = 1 scores the reference-side candidate fl + motif*i (no right flank) and also returns
 // the db position where the alignment ends (repeats.py:23-43).
@@ -530,9 +575,9 @@ int score_table_impl(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, 
     HIP_TRY(hipMemcpyAsync(a.win_n, n, nr * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(a.tab_off, off_dev.data(), nr * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, kCountersBytes, st));
-    HIP_TRY(hipEventRecord(ctx->ev[0], st));
+    HIP_TRY(hipEventRecord(ctx->ev[kEvStart], st));
     enqueue_scoring(ctx, a, 1, nullptr, batch->n_reads, force_generic, st, true);
-    HIP_TRY(hipEventRecord(ctx->ev[3], st));
+    HIP_TRY(hipEventRecord(ctx->ev[kEvEnd], st));
     HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -551,8 +596,8 @@ int score_table_impl(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, 
     }
     if (stats) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) stats->kernel_ms = ms;
-        if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) stats->dp_kernel_ms = ms;
+        if (hipEventElapsedTime(&ms, ctx->ev[kEvStart], ctx->ev[kEvEnd]) == hipSuccess) stats->kernel_ms = ms;
+        if (hipEventElapsedTime(&ms, ctx->ev[kEvWide], ctx->ev[kEvExact]) == hipSuccess) stats->dp_kernel_ms = ms;
         stats->n_dp_launches = 2;
         stats->n_fallback = ctx->h_counters[kCntClass0 + kGenericClass];
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->h_counters) + kCellsOff);
@@ -574,6 +619,18 @@ extern "C" {
 const char* strk_last_error(void) { return g_err.c_str(); }
 const char* strk_version(void) { return "strkit_amd 0.1.0 (gfx950)"; }
 
+int strk_device_mem(int device, int64_t* free_bytes, int64_t* total_bytes) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(STRK_E_NODEV, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(STRK_E_NODEV, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return 0;
+}
+
 int strk_init(int device, strk_ctx** out) {
     if (!out) return fail(STRK_E_INVALID, "out is NULL");
     *out = nullptr;
@@ -592,7 +649,7 @@ int strk_init(int device, strk_ctx** out) {
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(strk::c_mat), t.mat, sizeof t.mat);
     if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(strk::c_enc), t.enc, sizeof t.enc);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), kCountersBytes, hipHostMallocDefault);
-    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < kNumEvents && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
     if (e != hipSuccess) {
         strk_destroy(c);
         return fail(STRK_E_DEVICE, "context setup: %s", hipGetErrorString(e));
@@ -604,6 +661,8 @@ int strk_init(int device, strk_ctx** out) {
 void strk_destroy(strk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    pipe_destroy(c->pipe);
+    c->pipe = nullptr;
     DevBuf* bufs[] = {&c->read_locus, &c->win_lo, &c->win_n, &c->tab_off, &c->table, &c->cls_list, &c->band_recs, &c->counters,
                       &c->scratch, &c->state_i32, &c->state_f64, &c->spec, &c->rhash, &c->rep, &c->exact, &c->win_lo2, &c->win_n2, &c->tab_off2, &c->table2,
                       &c->items, &c->in_seqs, &c->in_seq_off, &c->in_nfl, &c->in_ntr, &c->in_nfr, &c->in_est,
@@ -646,6 +705,11 @@ int strk_count_loci_dseqs(strk_ctx* ctx, const strk_batch* batch, const void* d_
     if (stats) memset(stats, 0, sizeof *stats);
     strk_batch d;
     int rc;
+    if (!d_seqs) {   // host bases: large batches go through the pinned three-slot pipeline (strk_host_pipe.inc)
+        bool taken = false;
+        rc = count_loci_pipelined(ctx, batch, params, out_cn, out_score, out_n_iters, out_start, stats, &taken);
+        if (taken) return rc;
+    }
     if ((rc = upload_batch(ctx, batch, &d, nullptr, static_cast<const uint8_t*>(d_seqs)))) return rc;
     if (batch->n_reads == 0 || batch->n_loci == 0) return 0;
     if (!batch->est_cn) return fail(STRK_E_INVALID, "est_cn is NULL");
@@ -752,6 +816,22 @@ int strk_ref_repeat_count_batch(strk_ctx* ctx, int32_t n_loci, const int32_t* st
                      motifs + motif_off[i], m, ref_size[i], max_iters[i], local_search_range[i], step_size[i]);
     }
     return ref_repeat_count_batch_impl(ctx, jobs, vcf_anchor_size, respect_coords, out9);
+}
+
+int strk_realign_i16_flags(int32_t n_pairs, const int64_t* s1_off, const int64_t* s2_off, const int32_t* scores, int32_t* out_flags) {
+    if (n_pairs < 0) return fail(STRK_E_INVALID, "n_pairs < 0");
+    if (n_pairs == 0) return 0;
+    if (!s1_off || !s2_off || !scores || !out_flags) return fail(STRK_E_INVALID, "NULL argument");
+    constexpr int64_t kLimit = 32767 - 2;   // INT16_MAX less the largest matrix entry (align_matrix.py:15): parasail's head-room
+    for (int32_t p = 0; p < n_pairs; ++p) {
+        const int64_t n1 = s1_off[p + 1] - s1_off[p], n2 = s2_off[p + 1] - s2_off[p];
+        if (n1 < 0 || n2 < 0) return fail(STRK_E_INVALID, "pair %d: negative length", p);
+        int32_t f = 0;
+        if (2 * std::min(n1, n2) > kLimit) f |= STRK_I16_CELL_MAY_SATURATE;   // no cell of an alignment exceeds 2 * min(rows, columns)
+        if (scores[p] > kLimit) f |= STRK_I16_SCORE_SATURATES | STRK_I16_CELL_MAY_SATURATE;
+        out_flags[p] = f;
+    }
+    return 0;
 }
 
 // ---- host-side front end (no device work, no context) -------------------------------------------------------------

@@ -6,13 +6,13 @@ namespace strk {
 
 // ---------------------------------------------------------------------------------------------
 // Band kernel (see strk_search.h "Banded scoring with an exactness certificate").  Lanes own
-// DIAGONALS instead of columns: lane l of a group keeps the 16 diagonals d = dlo + 16 l .. + 15 of the
-// current row, so a group of 8 (16) lanes covers a band of 128 (256) diagonals that follows the
-// alignment down the matrix.  Per row and slot k:
-//     up   = (r-1, j)   = old[k+1]   (the next lane's NEW [0] for k = 15: it works one row behind; a DPP, mid-step)
-//     left = (r, j-1)   = new[k-1]   (the previous lane's new[15] for k = 0: the systolic skew)
+// DIAGONALS instead of columns: lane l of a group keeps the D diagonals d = dlo + D l .. + D - 1 of the
+// current row (D = 16; 12 in the narrow class), so a group of 8 (16) lanes covers a band
+// of 128 (256) diagonals that follows the alignment down the matrix.  Per row and slot k:
+//     up   = (r-1, j)   = old[k+1]   (the next lane's NEW [0] for k = D-1: it works one row behind; a DPP, mid-step)
+//     left = (r, j-1)   = new[k-1]   (the previous lane's new[D-1] for k = 0: the systolic skew)
 //     diag = (r-1, j-1) = old[k] + w
-// and the selector bytes of the lane's 16 columns slide by one column per row (four v_alignbyte plus
+// and the selector bytes of the lane's D columns slide by one column per row (D/4 v_alignbyte plus
 // one LDS byte).  Cells outside the band are 0 in G-space (= -inf: every real value is >= 0); the pad columns
 // left of column 1 and the rows in front of row 1 carry the boundary values by themselves (row-word tables below),
 // cells right of the last column replicate it.
@@ -25,7 +25,7 @@ struct BandLayout {
     int wd, pad, maxdb, maxcol, off_sel, off_cp, off_ct, off_b0, group_bytes, sel_len;
     static constexpr int OFF_COMB = 0, OFF_MISC = OFF_COMB + kTableMax * 4, OFF_LMAX = OFF_MISC + 16;
     static constexpr int kBandHiPad = kBandRowSlack + 32;
-    __host__ __device__ constexpr BandLayout(int c)   // c = band class
+    __host__ __device__ constexpr BandLayout(int c)   // c = layout class (band_class_layout: 0..3)
         : wd(128 << c), pad((128 << c) + (8 << c) + 8), maxdb(band_max_db(c)), maxcol(band_max_col(c)),
           off_sel(OFF_LMAX + (band_class_lmax(c) ? kTableMax * 4 : 0)),
           off_cp(off_sel + ((band_max_db(c) + 2 * ((128 << c) + (8 << c) + 8) + kBandHiPad + 15) & ~15)),
@@ -35,11 +35,13 @@ struct BandLayout {
           group_bytes(off_b0 + ((band_max_col(c) * 2 + 15) & ~15)),
           sel_len((band_max_db(c) + 2 * ((128 << c) + (8 << c) + 8) + kBandHiPad) & ~3) {}
 };
+static_assert(band_class_layout(kBandNarrowClass) == 0 && band_class_wd(kBandNarrowClass) <= 128 && band_class_G(kBandNarrowClass) == 8,
+              "the narrow class uses class 0's LDS layout: pads sized for 128 diagonals and 8 lanes cover it");
 __host__ __device__ constexpr int band_wave_lds(int c) { return (64 / (8 << c)) * BandLayout(c).group_bytes; }
 __host__ __device__ constexpr int max_band_wave_lds(int c) {
     return c < 0 ? 0 : (band_wave_lds(c) > max_band_wave_lds(c - 1) ? band_wave_lds(c) : max_band_wave_lds(c - 1));
 }
-constexpr int kBandWaveLds = max_band_wave_lds(kNumBandClasses - 1);
+constexpr int kBandWaveLds = max_band_wave_lds(3);   // layout classes 0..3
 constexpr int kBandNeg16 = -20000;
 // Fixed symbol classes of the band kernels: what an alignment file's reads hold after wildcarding (call_locus.py:79):
 // A C G T, N and the wildcard X, in either case.  v_perm selector = class index = bits 3:1 of the ASCII code (A 0, C 1, T 2,
@@ -106,25 +108,26 @@ __device__ __forceinline__ int from_right0(int v, int notLast) {
 // boundary values: the row-0 pattern above the last lane's first row (step G - 1) and the left-boundary column while it lies
 // right next to the band (step -dlo of each group; the pads further left carry the boundary by themselves, see the row-word
 // tables above).  Only the pairs of steps that hold one of those moments run the second form.
-template <int G, bool BWD, bool FLY, bool LMAX>
+template <int G, int D, bool BWD, bool FLY, bool LMAX>
 __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsym, int nrows, int dlo_, bool topFree,
                                           bool leftFree, int nEff, int fork0, int m, int cmin, int ncol, int* comb,
                                           short* b0col, int* lmaxA) {
-    constexpr int g = kGap;
+    static_assert(D % 4 == 0 && D >= 8 && D <= 16, "a lane keeps 8, 12 or 16 diagonals");
+    constexpr int g = kGap, NQ = D / 4;
     const int ncols = x.ndb;
-    const int d0 = dlo_ + x.lig * 16;                 // diagonal of this lane's slot 0
+    const int d0 = dlo_ + x.lig * D;                  // diagonal of this lane's slot 0
     auto g0 = [&](int j) -> int { return topFree ? g * min(max(j, 0), ncols) : 0; };   // row-0 pattern
     auto col_addr = [&](int j) -> int {               // LDS index of the class byte of column j (1-based)
         return BWD ? x.pad + ncols - j : x.pad + j - 1;   // always inside the padded array (BandLayout)
     };
-    int Ha[16], Hb[16];
-    unsigned sel[4];
+    int Ha[D], Hb[D];
+    unsigned sel[NQ];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) Ha[k] = g0(-x.lig + d0 + k);
+    for (int k = 0; k < D; ++k) Ha[k] = g0(-x.lig + d0 + k);
     const int jb0 = 1 - x.lig + d0;                   // column of slot 0 at the row of step 0 (step t: jb0 + t)
     {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             unsigned v = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) v |= (unsigned)x.selb[col_addr(jb0 + 4 * q + b)] << (8 * b);
@@ -132,14 +135,14 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         }
     }
     const int T = (wave_max_over_groups(nrows > 0 ? nrows + G - 1 : 0) + 1) & ~1;
-    const int dhi_ = dlo_ + 16 * G - 1;
-    int houtL = Ha[15];
+    const int dhi_ = dlo_ + D * G - 1;
+    int houtL = Ha[D - 1];
     // the step at which this lane finishes its next fork row (forward), its last row (backward: the one event of that pass)
     int forkT = (!BWD && nEff > 0) ? fork0 - 1 + x.lig : 0x7fffffff;
     if (BWD && nrows > 0) forkT = nrows - 1 + x.lig;
     int forkIdx = 0;
     // classes of band_class_lmax: running maximum of the last column over the in-band rows.  Right of column |db|
-    // the pads replicate G(r, |db|), so from row |db| - dhi on the last lane's slot 15 holds that value.
+    // the pads replicate G(r, |db|), so from row |db| - dhi on the last lane's last slot holds that value.
     int lastmax = kNegInf;
     int gr = -g * x.lig;                               // g * (row finished before step 0): LMAX only
     const int grFirst = g * max(1, ncols - dhi_);
@@ -166,8 +169,8 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     uint2 wordE, wordO;
     if (FLY) { wordE = row_word(next_sym()); wordO = row_word(next_sym()); }
     else { wordE = row_word(psym[0]); wordO = row_word(psym[1]); }
-    // class byte entering the lane's window after step t: column jb0 + t + 16
-    lds_cu8 pnb = (lds_cu8)(x.selb + col_addr(jb0 + 16)) - (BWD ? 1 : 0);
+    // class byte entering the lane's window after step t: column jb0 + t + D
+    lds_cu8 pnb = (lds_cu8)(x.selb + col_addr(jb0 + D)) - (BWD ? 1 : 0);
 #define STRK_BAND_STEP(SRC, DST, TT, ODD, EDGE)                                                    \
     {                                                                                              \
         STRK_BAND_FORK(SRC, (TT) - 1)                                                              \
@@ -185,18 +188,14 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         } else {                                                                                   \
             leftEdge = from_left0<G>(houtL, x.notFirst);                                           \
         }                                                                                          \
-        const unsigned w0 = __builtin_amdgcn_perm(word.y, word.x, sel[0]);                         \
-        const unsigned w1 = __builtin_amdgcn_perm(word.y, word.x, sel[1]);                         \
-        const unsigned w2 = __builtin_amdgcn_perm(word.y, word.x, sel[2]);                         \
-        const unsigned w3 = __builtin_amdgcn_perm(word.y, word.x, sel[3]);                         \
-        DST[0] = max(max(SRC[1], leftEdge), SRC[0] + (int)(w0 & 0xffu));                           \
+        unsigned wq[NQ];                                                                           \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) wq[q] = __builtin_amdgcn_perm(word.y, word.x, sel[q]); \
+        DST[0] = max(max(SRC[1], leftEdge), SRC[0] + (int)(wq[0] & 0xffu));                        \
         const int upEdge = (EDGE) ? from_right<G>(keepU, DST[0], x.last) : from_right0<G>(DST[0], x.notLast); \
-        _Pragma("unroll") for (int k = 1; k < 15; ++k) {                                           \
-            const unsigned wq = k < 4 ? w0 : (k < 8 ? w1 : (k < 12 ? w2 : w3));                     \
-            DST[k] = max(max(SRC[k + 1], DST[k - 1]), SRC[k] + (int)((wq >> (8 * (k % 4))) & 0xffu)); \
-        }                                                                                          \
-        DST[15] = max(max(upEdge, DST[14]), SRC[15] + (int)(w3 >> 24));                            \
-        houtL = DST[15];                                                                           \
+        _Pragma("unroll") for (int k = 1; k < D - 1; ++k)                                          \
+            DST[k] = max(max(SRC[k + 1], DST[k - 1]), SRC[k] + (int)((wq[k / 4] >> (8 * (k % 4))) & 0xffu)); \
+        DST[D - 1] = max(max(upEdge, DST[D - 2]), SRC[D - 1] + (int)(wq[NQ - 1] >> 24));           \
+        houtL = DST[D - 1];                                                                        \
         /* the two bytes as plain 32-bit values from here on (zero-extended by the load, which the compiler knows in   \
            this block only: their uses may be moved below the next fork-row branch) */                  \
         asm volatile("" : "+v"(nb), "+v"(sym2));                                                   \
@@ -204,10 +203,8 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
             gr += g;                                                                               \
             lastmax = (gr >= grFirst) ? max(lastmax, houtL - gr) : lastmax;                        \
         }                                                                                          \
-        sel[0] = __builtin_amdgcn_alignbyte(sel[1], sel[0], 1);                                    \
-        sel[1] = __builtin_amdgcn_alignbyte(sel[2], sel[1], 1);                                    \
-        sel[2] = __builtin_amdgcn_alignbyte(sel[3], sel[2], 1);                                    \
-        sel[3] = __builtin_amdgcn_alignbyte(nb, sel[3], 1);                                        \
+        _Pragma("unroll") for (int q = 0; q + 1 < NQ; ++q) sel[q] = __builtin_amdgcn_alignbyte(sel[q + 1], sel[q], 1); \
+        sel[NQ - 1] = __builtin_amdgcn_alignbyte(nb, sel[NQ - 1], 1);                              \
         if (ODD) wordO = row_word(sym2); else wordE = row_word(sym2);                              \
     }
     // the fork-row work of step TT on that step's output row V.  It runs at the head of the NEXT step, so that a step
@@ -217,7 +214,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         const int jb = jb0 + (TT);                      /* column of slot 0 at that step's row */  \
         if (BWD) {                                                                                 \
             /* last row: slot k is reversed column jb + k, i.e. db node ndb - (jb + k) */           \
-            _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                       \
+            _Pragma("unroll") for (int k = 0; k < D; ++k) {                                        \
                 const int jp = jb + k, idx = ncols - jp - cmin;                                    \
                 if (jp >= 0 && jp <= ncols && idx >= 0 && idx < ncol) b0col[idx] = (short)V[k];    \
             }                                                                                      \
@@ -225,7 +222,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         } else {                                                                                   \
             const short* bc = b0col + (jb - cmin);                                                 \
             int acc = kNegInf;                                                                     \
-            _Pragma("unroll") for (int k = 0; k < 16; k += 2)                                      \
+            _Pragma("unroll") for (int k = 0; k < D; k += 2)                                       \
                 acc = max(max(acc, V[k] + (int)bc[k]), V[k + 1] + (int)bc[k + 1]);                 \
             atomicMax(&comb[forkIdx], acc);                                                        \
             if (LMAX && x.last) lmaxA[forkIdx] = lastmax;                                          \
@@ -280,17 +277,17 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
 #define STRK_PHASE(i) do { } while (0)
 #endif
 
-// Processes 64/G items of band class BC (G = 8 << BC lanes per read), one per group.
+// Processes 64/G items of band class BC (G = band_class_G(BC) lanes per read), one per group.
 // nextA / nextB / nextC: the caller's three steps towards the NEXT chunk (take it from the queue; fetch its records; touch its
 // window bytes), called where each one's result has had time to arrive and where its own loads are not in the way of this
 // chunk's (the memory counter retires loads in order: a load issued behind a slow one waits for it).
 template <int BC, class NA, class NB, class NC>
 __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int4 q1, int4 q2, uint8_t* Lw, const uint8_t* s_enc,
                                           const uint8_t* s_tbl, NA& nextA, NB& nextB, NC& nextC) {
-    constexpr int g = kGap, G = 8 << BC;
+    constexpr int g = kGap, G = band_class_G(BC), D = band_class_D(BC);
     constexpr bool FLY = band_class_fly(BC);
     constexpr bool LMAX = band_class_lmax(BC);
-    constexpr BandLayout lay(BC);
+    constexpr BandLayout lay(band_class_layout(BC));
     const int lane = threadIdx.x & 63;
 #ifdef STRK_PHASE_TIMING
     unsigned long long tphase = __builtin_readcyclecounter();
@@ -426,12 +423,12 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     const int nEff = run ? n : 0;
     // backward pass (reversed right flank x reversed window), then forward pass with the fork rows
     x.tbl = s_tbl + kBandTblBytes;
-    band_pass<G, true, false, false>(x, ct, (run && !(a.dbg & 2)) ? rowsT : 0, geo.bdlo, dbEnd, cEnd, 0, 0, 1, geo.cmin, geo.ncol, comb, b0col, lmaxA);
+    band_pass<G, D, true, false, false>(x, ct, (run && !(a.dbg & 2)) ? rowsT : 0, geo.bdlo, dbEnd, cEnd, 0, 0, 1, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
     nextC();
     STRK_PHASE(3);
     x.tbl = s_tbl;
-    band_pass<G, false, FLY, LMAX>(x, cp, (run && !(a.dbg & 1)) ? rowsP : 0, geo.dlo, dbBeg, cBeg, (a.dbg & 8) ? 0 : nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col, lmaxA);
+    band_pass<G, D, false, FLY, LMAX>(x, cp, (run && !(a.dbg & 1)) ? rowsP : 0, geo.dlo, dbBeg, cBeg, (a.dbg & 8) ? 0 : nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
     STRK_PHASE(4);
     if (run) {
@@ -481,15 +478,18 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     STRK_PHASE(5);
 }
 
-// Two kernels so that the common short classes (0, 1) are not register-allocated together with the
-// long-window classes (2, 3).  SET 0: classes 1 then 0;  SET 1: classes 3 then 2.  Each wave pulls chunks
-// from the set's queue until it is empty.
+// Two kernels so that the common short classes (0, 1, narrow) are not register-allocated together with the long-window
+// classes (2, 3).  k_dp_band must stay within 208 VGPRs: k_replay and the other helper kernels of the calls in flight
+// (<= 96 VGPRs, no LDS) then fit next to two of its waves on a SIMD (216 + 216 + 96 > 512: 152 M reads/s instead of 216 M).
+// SET 0: classes 1, 0, then the narrow class;  SET 1: classes 3, 2.  Each wave pulls chunks from the set's queue until it is
+// empty (chunks of the most expensive class first).
 template <int SET>
 __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
-    constexpr int CA = SET ? 3 : 1, CB = SET ? 2 : 0;   // wider class first
+    constexpr int CA = SET ? 3 : 1, CB = SET ? 2 : 0, CC = SET ? -1 : kBandNarrowClass;
     const int nA = min(a.counters[kCntClass0 + kBandClass0 + CA], a.list_stride);
     const int nB = min(a.counters[kCntClass0 + kBandClass0 + CB], a.list_stride);
-    if (nA + nB <= 0) return;
+    const int nC = CC >= 0 ? min(a.counters[kCntClass0 + kBandClass0 + (CC >= 0 ? CC : 0)], a.list_stride) : 0;
+    if (nA + nB + nC <= 0) return;
     // the two row-word tables sit in front of the per-wave regions
     constexpr int kTblBytes = 2 * kBandTblBytes;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kTblBytes + 4 * kBandWaveLds + kLdsSlack];
@@ -520,8 +520,9 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
     }
     __syncthreads();
     uint8_t* const Lw = lds + kTblBytes + (threadIdx.x >> 6) * kBandWaveLds;
-    constexpr int perA = 64 / (8 << CA), perB = 64 / (8 << CB);   // reads per wave
-    const int chA = (nA + perA - 1) / perA, chB = (nB + perB - 1) / perB;
+    constexpr int GA = band_class_G(CA), GB = band_class_G(CB), GC = band_class_G(CC >= 0 ? CC : 0);
+    constexpr int perA = 64 / GA, perB = 64 / GB, perC = 64 / GC;   // reads per wave
+    const int chA = (nA + perA - 1) / perA, chB = (nB + perB - 1) / perB, chC = (nC + perC - 1) / perC;
     const int lane = threadIdx.x & 63;
     auto pop = [&]() {
         int c = 0;
@@ -531,22 +532,21 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
     // record of this lane's item in chunk c (chunks of the wider class come first)
     auto fetch = [&](int c, bool& act, int4& q0, int4& q1, int4& q2) -> int {
         int cls = CA, it = 0, cnt = 0;
-        if (c < chA) { cls = CA; it = c * perA + lane / (8 << CA); cnt = nA; }
-        else if (c - chA < chB) { cls = CB; it = (c - chA) * perB + lane / (8 << CB); cnt = nB; }
+        if (c < chA) { cls = CA; it = c * perA + lane / GA; cnt = nA; }
+        else if (c - chA < chB) { cls = CB; it = (c - chA) * perB + lane / GB; cnt = nB; }
+        else if (c - chA - chB < chC) { cls = CC; it = (c - chA - chB) * perC + lane / GC; cnt = nC; }
         act = it < cnt;
         if (act) {
             const int4* rec = a.band_recs + ((size_t)cls * a.list_stride + it) * 3;
             q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
         }
-        return 8 << cls;   // lanes per item of that chunk
+        return band_class_G(cls);   // lanes per item of that chunk
     };
     // Touch the window bytes of an item one chunk early (one byte per 64-byte line, a line per lane of the group), so
     // that the staging loop of its chunk finds them in cache.  The loaded byte itself is never used.
-    auto touch = [&](bool act_, const int4& q0_, const int4& q1_, const int4& q2_, int G_) -> unsigned {
+    auto touch = [&](bool act_, long long so, int ndb_, int G_) -> unsigned {
         unsigned sink = 0;
         if (act_) {
-            const long long so = (long long)(((unsigned long long)(unsigned)q2_.y << 32) | (unsigned)q2_.x);
-            const int ndb_ = q0_.z + q0_.w + q1_.x;
             const uint8_t* pp = a.seqs + so + min((lane & (G_ - 1)) * 64, max(ndb_ - 1, 0));
             asm volatile("global_load_ubyte %0, %1, off" : "=v"(sink) : "v"(pp) : "memory");
         }
@@ -556,21 +556,32 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
     bool act = false;
     int4 q0 = make_int4(0, 0, 0, 0), q1 = q0, q2 = q0;
     (void)fetch(c, act, q0, q1, q2);
-    while (c < chA + chB) {
+    while (c < chA + chB + chC) {
         __builtin_amdgcn_wave_barrier();   // the wave enters every iteration whole (see k_realign_dp)
-        // the next chunk is taken, its records are fetched and its window bytes touched while this one is being processed
-        int cn_raw = 0, cn = 0, g_n = 8;
+        // the next chunk is taken, its records are fetched and its window bytes touched while this one is being processed.
+        // Of the records only what the touch needs stays in registers across the two passes (three values, not twelve: the
+        // passes are where the kernel's register allocation peaks); the records themselves are fetched again, from cache,
+        // when this chunk is done.
+        int cn_raw = 0, cn = 0, g_n = 8, ndb_n = 0;
+        long long so_n = 0;
         bool act_n = false;
-        int4 n0 = make_int4(0, 0, 0, 0), n1 = n0, n2 = n0;
         unsigned sink = 0;
         auto nextA = [&]() { if (lane == 0) cn_raw = atomicAdd(&a.counters[kCntNextBand + SET], 1); };
-        auto nextB = [&]() { cn = __builtin_amdgcn_readfirstlane(cn_raw); g_n = fetch(cn, act_n, n0, n1, n2); };
-        auto nextC = [&]() { sink = touch(act_n, n0, n1, n2, g_n); };
+        auto nextB = [&]() {
+            int4 n0 = make_int4(0, 0, 0, 0), n1 = n0, n2 = n0;
+            cn = __builtin_amdgcn_readfirstlane(cn_raw);
+            g_n = fetch(cn, act_n, n0, n1, n2);
+            so_n = (long long)(((unsigned long long)(unsigned)n2.y << 32) | (unsigned)n2.x);
+            ndb_n = n0.z + n0.w + n1.x;
+        };
+        auto nextC = [&]() { sink = touch(act_n, so_n, ndb_n, g_n); };
         if (c < chA) band_wave<CA>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
-        else band_wave<CB>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
+        else if (CC < 0 || c < chA + chB) band_wave<CB>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
+        else band_wave<(CC >= 0 ? CC : CB)>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
+        c = cn;
+        (void)fetch(c, act, q0, q1, q2);
         // the touch load's destination register stays reserved until the load has certainly landed
         asm volatile("s_waitcnt vmcnt(0)" : : "v"(sink) : "memory");
-        c = cn; act = act_n; q0 = n0; q1 = n1; q2 = n2;
     }
 }
 // two blocks (eight waves) per CU: the register allocation must stay within 256 VGPRs

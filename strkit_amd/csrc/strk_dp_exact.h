@@ -9,6 +9,7 @@ namespace strk {
 // ---------------------------------------------------------------------------------------------
 constexpr int kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;  // gfx9 DPP controls, present on gfx950
 constexpr int kCLMax = 40;   // columns per lane of the largest class
+constexpr int kStairMinG = 32;   // classes with at least this many lanes per read fold fork rows along a staircase (bwd_pass)
 constexpr int kNQMax = kCLMax / 4;
 
 constexpr int kDppRowShr1 = 0x111, kDppRowShl1 = 0x101;
@@ -46,7 +47,7 @@ __device__ __forceinline__ int wave_max_over_groups(int v) {
 
 // Per-group LDS layout of a class (G lanes x CL columns); all offsets are multiples of 16.
 struct DpLayout {
-    int cap, off_db, off_cp, off_ct, off_b0, group_bytes;
+    int cap, off_db, off_cp, off_ct, off_b0, off_bj, group_bytes;
     static constexpr int OFF_TBL = 0;                          // 18 x 8 B row words
     static constexpr int OFF_COMB = OFF_TBL + 18 * 8;          // kTableMax ints
     static constexpr int OFF_LMAX = OFF_COMB + kTableMax * 4;  // kTableMax ints
@@ -57,7 +58,8 @@ struct DpLayout {
           off_cp(off_db + ((G * CL + 8 + 15) & ~15)),                        // prefix rows
           off_ct(off_cp + ((G * CL + kRowSlack + 2 * G + 4 + 15) & ~15)),    // tail rows (reversed fr)
           off_b0(off_ct + ((kFastFlankMax + 2 * G + 4 + 15) & ~15)),         // backward result, u16 per slot
-          group_bytes(off_b0 + ((G * CL * 2 + 15) & ~15)) {}
+          off_bj(off_b0 + ((G * CL * 2 + 15) & ~15)),                        // staircase fork rows: one int per lane
+          group_bytes(off_bj + ((G * 4 + 15) & ~15)) {}
 };
 __host__ __device__ constexpr int wave_lds_bytes(int c) { return (64 / class_G(c)) * DpLayout(class_G(c), class_CL(c)).group_bytes; }
 __host__ __device__ constexpr int max_wave_lds_bytes(int c) {
@@ -77,6 +79,7 @@ struct PassCtx {
     const uint2* tbl;        // LDS: per-symbol row words
     const unsigned* selw;    // LDS: selector words of this lane, selw[q] <-> db[lig*CL + 4q - 4 .. -1]
     uint2* b0;               // LDS: backward result of this lane, b0[q * G] <-> slots 4q..4q+3 (u16 each)
+    int* bj;                 // LDS: staircase fork rows, this lane's first slot one backward row before its b0 row
 };
 
 // One DP row in G-space over the lane's 4*NQ columns: dst = max3(up, left, diag + w).  FWD walks
@@ -98,7 +101,17 @@ __device__ __forceinline__ int dp_row(const int (&src)[4 * NQ], int (&dst)[4 * N
 // Backward pass over the fr rows (k' = 1..rowsT consume fr[rowsT-k']).  Slot s holds node j = s
 // (db chars s.. remain) for s < ndb; slots >= ndb are inert pads that carry the boundary value.
 // Leaves Gb(rowsT, .) in LDS (b0) and returns max_{k'<rowsT} (Gb(k', 0) - g*k') for lane 0.
-template <int NQ, int G>
+//
+// STAIR (staircase fork rows, classes of 32 and 64 lanes per read): the forward pass then folds a fork row when its FIRST lane
+// finishes it, lane l standing l rows above it — the cut through the matrix is a staircase, and lane l needs the backward
+// values of a suffix that still holds the last l rows in front of the fork row.  Those rows are motif rows (the caller
+// checks (smallest candidate) * |motif| >= G - 1) and, a fork row sitting at the end of a motif copy, the same for every
+// candidate: the reversed motif, cyclically.  The backward pass simply runs on over them (row symbols staged behind the
+// reversed right flank): lane l works G - 1 - l rows behind the last lane, so row rowsT + l of lane l is the pass's LAST
+// step for every lane — the skew steps that used to compute nothing now compute the extension, and the result is stored
+// once, by all lanes together, instead of at G different steps.  One value more per lane: its first slot one row earlier
+// (bj), for the one transition the staircase cut does not see (fwd_pass).
+template <int NQ, int G, bool STAIR>
 __device__ __forceinline__ int bwd_pass(const PassCtx& x, int rowsT, const uint8_t* ct) {
     constexpr int g = kGap, CL = 4 * NQ;
     int Ha[CL], Hb[CL];
@@ -114,7 +127,7 @@ __device__ __forceinline__ int bwd_pass(const PassCtx& x, int rowsT, const uint8
     }
     const int Tb = (wave_max_over_groups(rowsT > 0 ? rowsT + G - 1 : 0) + 1) & ~1;
     const int bstep = x.cEnd ? g : 0;
-    const int gkEvent = g * rowsT;
+    const int gkEvent = g * (rowsT + (STAIR ? x.lig : 0));   // STAIR: every lane of a group reaches its row at step rowsT + G - 2
     int zsave = 0;
     int hout = Ha[0];
     int edgePrev = from_right<G>(0, hout, x.last);
@@ -136,6 +149,7 @@ __device__ __forceinline__ int bwd_pass(const PassCtx& x, int rowsT, const uint8
             _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                   \
                 x.b0[q * G] = make_uint2((unsigned)DST[4 * q] | ((unsigned)DST[4 * q + 1] << 16), \
                                          (unsigned)DST[4 * q + 2] | ((unsigned)DST[4 * q + 3] << 16)); \
+            if (STAIR) *x.bj = SRC[0];                                                       \
             zsave = zmax;                                                                    \
         }                                                                                    \
         zmax = max(zmax, hout - gk);                                                         \
@@ -153,7 +167,16 @@ __device__ __forceinline__ int bwd_pass(const PassCtx& x, int rowsT, const uint8
 // s = 1..ndb holds node j = s (consumes db[s-1]); slots > ndb replicate the last column.  At the
 // fork rows R_k = nfl + (lo+k)*m it folds max_s(Gf + Gb) into comb[k] and records the running
 // last-column maximum in lmaxA[k].
-template <int NQ, int G>
+//
+// STAIR: a fork row is folded at the step at which the group's first lane finishes it (one execution of the fork block per
+// fork row and group, every lane taking part, instead of one per lane and fork row); lane l then stands at row R_k - l and
+// adds the backward values of the suffix "last l motif rows + right flank" (bwd_pass).  Every alignment passes through one
+// cell of that staircase — a monotone path leaves the region above it exactly once, and its last cell above is a cut cell —
+// with ONE exception: the diagonal step from the last column of lane l - 1, one row above that lane's cut row, into the
+// first column of lane l, one row below lane l's cut row.  Lane l folds that transition by itself: the left neighbour's
+// value is its own edge input of this step, the substitution score comes from its next row's word, and the backward value
+// of the cell entered is its first slot one backward row earlier (bj).
+template <int NQ, int G, bool STAIR>
 __device__ __forceinline__ void fwd_pass(const PassCtx& x, int rowsP, const uint8_t* cp, int nEff, int fork0, int m,
                                          int* comb, int* lmaxA) {
     constexpr int g = kGap, CL = 4 * NQ;
@@ -170,8 +193,9 @@ __device__ __forceinline__ void fwd_pass(const PassCtx& x, int rowsP, const uint
     int edgePrev = from_left<G>(0, hout, x.first);
     int gr = -g * x.lig;           // g * row this lane finished before step 0
     int lastmax = kNegInf;
-    int forkG = nEff > 0 ? g * fork0 : 0x7fffffff;
+    int forkG = nEff > 0 ? g * (fork0 - (STAIR ? x.lig : 0)) : 0x7fffffff;
     int forkIdx = 0;
+    const int bjump = STAIR ? (x.first ? kNegInf : *x.bj) : 0;
     const uint8_t* pa = cp + (G - 1) - x.lig;
     uint2 wordNext = x.tbl[pa[0]];
     unsigned symNext = pa[1];
@@ -193,6 +217,8 @@ __device__ __forceinline__ void fwd_pass(const PassCtx& x, int rowsP, const uint
                 acc = max(max(acc, DST[4 * q] + (int)(bw.x & 0xffffu)), DST[4 * q + 1] + (int)(bw.x >> 16)); \
                 acc = max(max(acc, DST[4 * q + 2] + (int)(bw.y & 0xffffu)), DST[4 * q + 3] + (int)(bw.y >> 16)); \
             }                                                                                \
+            if (STAIR)                                                                       \
+                acc = max(acc, edgePrev + (int)(__builtin_amdgcn_perm(wordNext.y, wordNext.x, sel[0]) & 0xffu) + bjump); \
             atomicMax(&comb[forkIdx], acc);                                                  \
             if (x.last) lmaxA[forkIdx] = lastmax;                                            \
             ++forkIdx;                                                                       \
@@ -314,6 +340,9 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     const int rowsP = act ? nfl + (lo + n - 1) * m : 0;
     constexpr int ref_mode = REF ? 1 : 0;   // k_dp_ref (reference side) / k_dp_all (reads)
     const int rowsT = (act && !ref_mode) ? nfr : 0;
+    // staircase fork rows (bwd_pass / fwd_pass): every item of the chunk must have G - 1 motif rows in its smallest candidate
+    const bool stair = !ref_mode && G >= kStairMinG && !(ap->dbg & 32) &&
+                       __builtin_amdgcn_ballot_w64(act && (long long)lo * m < G - 1) == 0;
 
     // ---- stage the encoded read window and collect its symbol set ------------------------------
     uint8_t* const motifL = Lg + lay.off_b0;   // encoded motif; the area is free until the backward pass ends
@@ -402,6 +431,7 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
             const int row = idx - (G - 1);  // backward row k' - 1
             int sym = kNullSym;
             if (row >= 0 && row < rowsT) sym = dbs[4 + ndb - 1 - row];
+            else if (stair && row >= rowsT && row < rowsT + G - 1) sym = motifL[m - 1 - (row - rowsT) % m];   // the reversed motif, cyclically
             ct[idx] = (uint8_t)sym;
         }
     }
@@ -428,15 +458,23 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     x.tbl = tbl;
     x.selw = reinterpret_cast<const unsigned*>(dbs) + lig * nq;
     x.b0 = reinterpret_cast<uint2*>(Lg + lay.off_b0) + lig;
+    x.bj = reinterpret_cast<int*>(Lg + lay.off_bj) + lig;
 
     // the two hot loops are specialised on (CL/4, G): 14 instances each, everything else is one body
     int zsave = 0;
     const int fork0 = nfl + lo * m;
-#define STRK_PASSES(NQ_, G_)                                             \
-    {                                                                    \
-        zsave = bwd_pass<NQ_, G_>(x, rowsT, ct);                          \
-        if (first) misc[1] = zsave;                                      \
-        fwd_pass<NQ_, G_>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA);     \
+#define STRK_PASSES(NQ_, G_)                                                     \
+    {                                                                            \
+        if (G_ >= kStairMinG && stair) {                                         \
+            zsave = bwd_pass<NQ_, G_, (G_ >= kStairMinG)>(x, rowsT, ct);          \
+            if (first) misc[1] = zsave;                                          \
+            wave_lds_sync();                                                     \
+            fwd_pass<NQ_, G_, (G_ >= kStairMinG)>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA); \
+        } else {                                                                 \
+            zsave = bwd_pass<NQ_, G_, false>(x, rowsT, ct);                       \
+            if (first) misc[1] = zsave;                                          \
+            fwd_pass<NQ_, G_, false>(x, rowsP, cp, nEff, fork0, m, comb, lmaxA);  \
+        }                                                                        \
     }
     if constexpr (REF) {
         fwd_pass_ref<7, 64>(x, rowsP, cp, nEff, fork0, m, reinterpret_cast<unsigned long long*>(comb));

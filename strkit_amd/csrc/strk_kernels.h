@@ -49,7 +49,7 @@ __host__ __device__ constexpr int class_CL(int c) {
 __host__ __device__ constexpr int class_cap(int c) { return class_G(c) * class_CL(c); }
 constexpr int kLongClass = kNumClasses;         // list of the column-tiled long-read kernel (k_dp_long)
 constexpr int kGenericClass = kNumClasses + 1;  // list of the generic kernel
-constexpr int kBandClass0 = kNumClasses + 2;    // band kernel lists: + class (G = 8 << class lanes, 16 G diagonals)
+constexpr int kBandClass0 = kNumClasses + 2;    // band kernel lists: + class (strk_search.h: band_class_G lanes x band_class_D diagonals)
 constexpr int kNumLists = kNumClasses + 2 + kNumBandClasses;
 constexpr int kLongTile = 64 * 28;              // slots per column tile of k_dp_long (G = 64, CL = 28)
 constexpr int kLongMaxTiles = 64;               // |db| + 1 <= 114 688
@@ -81,7 +81,8 @@ struct KArgs {
                           //   (read, locus, nfl, ntr) (nfr, m, lo, n) (seq_off lo, seq_off hi, motif_off, est_cn)
     int32_t* counters;    // see Counter enum
     unsigned long long* cells;  // DP cells executed; cells[2] / cells[3]: algorithmic bytes (|window| + 16 per read) of the
-                                // items routed to the band kernel / to the exact kernels by k_plan
+                                // items routed to the band kernels / to the exact kernels by k_plan; cells[4] / cells[5]: the part
+                                // of those that k_dp_band_wide / k_dp_long take
     int32_t* scratch;     // generic kernel rows
     long long scratch_cap;      // in int32 units; [0, long_waves * long_slot) belongs to k_dp_long (one slot
                                 //   per resident wave), the rest is handed out by the generic kernel's bump allocator
@@ -93,7 +94,9 @@ struct KArgs {
     int32_t* rep;         // [n_reads] earliest identical read of the same locus (itself if none)
     int32_t list_stride;
     int32_t end_flags;
-    int32_t window;       // half width (plan kernel)
+    int32_t window;       // half width (plan kernel): the largest of window_b
+    int32_t window_b[4];  // ... per motif-length bucket (win_bucket): the estimate round(|tr| / |motif|) is off by the read's
+                          //    indel drift DIVIDED by the motif length, so long motifs get by with narrow windows
     int32_t table_stride; // entries per read (plan kernel)
     int32_t max_iters, lsr, step, tie_last;  // search parameters (speculative search in k_dp_all)
     int32_t band_mode;    // 1: eligible reads go through k_dp_band first (strk_search.h, "Banded scoring")
@@ -114,8 +117,12 @@ enum Counter {
     kCntNextLong = kNumLists + 4,         // work queue head of k_dp_long
     kCntNextBand = kNumLists + 5,         // work queue heads of k_dp_band (+0) and k_dp_band_wide (+1)
     kCntBandFallback = kNumLists + 7,     // band reads whose search could not be certified (re-scored exactly)
-    kCntTotal = kNumLists + 8
+    kCntMissB = kNumLists + 8,            // [4] loci whose search left the table window, per motif-length bucket
+    kCntLociB = kNumLists + 12,           // [4] loci per motif-length bucket
+    kCntTotal = kNumLists + 16
 };
+// motif-length buckets of the adaptive candidate window: 1-2, 3-4, 5-8, 9 and more bases
+__host__ __device__ constexpr int win_bucket(int m) { return m <= 2 ? 0 : (m <= 4 ? 1 : (m <= 8 ? 2 : 3)); }
 constexpr int kErrBadInput = 1;   // empty motif / negative length
 constexpr int kErrScratch = 2;    // generic scratch exhausted
 constexpr int kErrEmpty = 4;      // nothing scored for some read
@@ -206,10 +213,10 @@ __device__ inline bool same_read(const KArgs& a, int r, int q) {
 __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* items, int n_items, int force_generic) {
     __shared__ int s_cnt[kNumLists];
     __shared__ int s_base[kNumLists];
-    __shared__ unsigned long long s_cells, s_bytes_band, s_bytes_exact;
+    __shared__ unsigned long long s_cells, s_bytes_band, s_bytes_exact, s_bytes_wide, s_bytes_long;
     __shared__ unsigned long long s_key[256];
     if (threadIdx.x < kNumLists) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_cells = 0; s_bytes_band = 0; s_bytes_exact = 0; }
+    if (threadIdx.x == 0) { s_cells = 0; s_bytes_band = 0; s_bytes_exact = 0; s_bytes_wide = 0; s_bytes_long = 0; }
     __syncthreads();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int r = 0, l = 0, nfl = 0, ntr = 0, nfr = 0, m = 1, lo = 0, n = 0;
@@ -233,7 +240,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
             const long long est = a.est_cn[r];
             // the estimate round(|tr| / |motif|) drifts with the copy number (indels accumulate): widen the
             // window by one size per 128 copies, as far as the table stride allows
-            const long long w = min((long long)a.window + min(max(est, 0ll) >> 7, 7ll), (long long)(a.table_stride - 1) / 2);
+            const long long w = min((long long)a.window_b[win_bucket(m)] + min(max(est, 0ll) >> 7, 7ll), (long long)(a.table_stride - 1) / 2);
             long long w_lo = est - w, w_hi = est + w;
             if (w_lo < 0) w_lo = 0;
             if (w_hi < w_lo) w_hi = w_lo;  // negative estimates: keep a one-entry window at 0
@@ -271,14 +278,16 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
         if (geo.ok) band_list = kBandClass0 + geo.cls;
     }
     if (a.exact && gid < n_items && n > 0) a.exact[r] = band_list < 0;
+    int first_c = -1;
     for (int k0 = 0; k0 < n; k0 += kTableMax) {
         const int nn = min(kTableMax, n - k0);
         const int c = band_list >= 0 ? band_list : classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic, a.ref_mode);
+        if (k0 == 0) first_c = c;
         atomicAdd(&s_cnt[c], 1);
         if (c == kGenericClass) {
             for (int k = 0; k < nn; ++k) cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + k) * m + nfr);
         } else if (band_list >= 0) {
-            cells += (unsigned long long)(128 << (band_list - kBandClass0)) * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
+            cells += (unsigned long long)band_class_wd(band_list - kBandClass0) * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
         } else {
             cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
         }
@@ -286,6 +295,8 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     if (cells) {
         atomicAdd(&s_cells, cells);
         atomicAdd(band_list >= 0 ? &s_bytes_band : &s_bytes_exact, ndb + 16);
+        if (band_list >= kBandClass0 + 2 && band_list <= kBandClass0 + 3) atomicAdd(&s_bytes_wide, ndb + 16);   // k_dp_band_wide's classes
+        if (first_c == kLongClass) atomicAdd(&s_bytes_long, ndb + 16);
     }
     __syncthreads();
     if (threadIdx.x < kNumLists) {
@@ -297,6 +308,8 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
         atomicAdd(a.cells, s_cells);
         if (s_bytes_band) atomicAdd(a.cells + 2, s_bytes_band);
         if (s_bytes_exact) atomicAdd(a.cells + 3, s_bytes_exact);
+        if (s_bytes_wide) atomicAdd(a.cells + 4, s_bytes_wide);
+        if (s_bytes_long) atomicAdd(a.cells + 5, s_bytes_long);
     }
     __syncthreads();
     // Band items of a block are listed in the order of (band class, prefix rows): the band kernel runs the 8 (4, 2, 1) items of

@@ -25,7 +25,7 @@ struct ReplayArgs {
 // in-order chain over the reads is wave-uniform ALU work on values fetched with v_readlane.
 // (at most 96 VGPRs: a wave of this kernel then fits next to the two resident waves of a band kernel on a SIMD, so that the
 // replay of one call runs inside the band pass of the next one instead of waiting for a free CU slot)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(96))) k_replay(KArgs a, ReplayArgs p) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) k_replay(KArgs a, ReplayArgs p) {
     const int l = blockIdx.x;
     const int lane = threadIdx.x;
     const int r_end = a.read_off[l + 1];
@@ -105,6 +105,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(96))) k_rep
     if (lane == 0) {
         p.next_read[l] = r_next;
         p.frac[l] = frac;
+        // per motif-length bucket: loci, and loci whose search left its window (the host adapts each bucket's default window)
+        const int bkt = win_bucket(a.motif_off[l + 1] - a.motif_off[l]);
+        atomicAdd(&a.counters[kCntLociB + bkt], 1);
+        if (missed) atomicAdd(&a.counters[kCntMissB + bkt], 1);
     }
 }
 

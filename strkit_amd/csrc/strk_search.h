@@ -122,30 +122,40 @@ STRK_HD SearchResult search_replay(int32_t start, int32_t step, int32_t lsr, int
 // ---------------------------------------------------------------------------------------------
 struct BandGeo {
     int32_t ok;      // eligible for the band kernel
-    int32_t cls;     // band class 0..3: G = 8 << cls lanes per read, 16 diagonals per lane
+    int32_t cls;     // band class 0..4 (band_class_G / band_class_D)
     int32_t G;
-    int32_t wd;      // band width in diagonals = 16 * G (128, 256, 512, 1024)
+    int32_t wd;      // forward band width in diagonals = D * G (128, 256, 512, 1024; 96 for the narrow class)
     int32_t dlo;     // forward band: d in [dlo, dlo + wd)
-    int32_t bdlo;    // backward band (reversed coordinates): delta in [bdlo, bdlo + wd)
+    int32_t bwd;     // backward band width (= wd: in original diagonals the backward band must hold diagonal 0 AND the end
+                     //   corner's, with the same slack as the forward band, or the 2 * len(diagonal) bound is void)
+    int32_t bdlo;    // backward band (reversed coordinates): delta in [bdlo, bdlo + bwd)
     int32_t cmin;    // first db node column the fork rows can touch
     int32_t ncol;    // number of such columns: (n - 1) * m + wd
 };
 
+// Band classes: 0..3 = 8 << c lanes per read x 16 diagonals per lane; 4 = the narrow class, 8 lanes x 12 diagonals, for
+// short motifs (the candidate sizes of a window of +-W span 2 W |motif| diagonals: motifs of up to 4 bases leave a band of
+// 96 as much slack as longer ones have in 128).
 // Per-class limits (what the class's LDS layout holds).  Classes 2 and 3 generate the forward row
 // symbols on the fly (left flank <= 255 rows from LDS, then the motif with a running phase).
-constexpr int kNumBandClasses = 4;
-STRK_HD constexpr int band_class_G(int c) { return 8 << c; }
-STRK_HD constexpr int band_max_db(int c) { return c == 0 ? 448 : (c == 1 ? 1024 : (c == 2 ? 4096 : 12288)); }
-STRK_HD constexpr int band_max_col(int c) { return c == 0 ? 320 : (c == 1 ? 512 : (c == 2 ? 1024 : 1536)); }
-STRK_HD constexpr bool band_class_fly(int c) { return c >= 2; }
+constexpr int kNumBandClasses = 5;
+constexpr int kBandNarrowClass = 4;
+STRK_HD constexpr int band_class_G(int c) { return c == kBandNarrowClass ? 8 : 8 << c; }
+STRK_HD constexpr int band_class_D(int c) { return c == kBandNarrowClass ? 12 : 16; }
+STRK_HD constexpr int band_class_wd(int c) { return band_class_G(c) * band_class_D(c); }
+STRK_HD constexpr int band_class_layout(int c) { return c == kBandNarrowClass ? 0 : c; }   // the narrow class lives in class 0's LDS layout
+STRK_HD constexpr int band_max_db(int c) { return (c == 0 || c == kBandNarrowClass) ? 448 : (c == 1 ? 1024 : (c == 2 ? 4096 : 12288)); }
+STRK_HD constexpr int band_max_col(int c) { return (c == 0 || c == kBandNarrowClass) ? 320 : (c == 1 ? 512 : (c == 2 ? 1024 : 1536)); }
+STRK_HD constexpr bool band_class_fly(int c) { return c == 2 || c == 3; }
 // classes that track the running maximum of the last column (alignments that end there above the fork row): all but the
-// narrowest one, where the bound on those alignments never reaches a good read's score (motifs of up to ~9 bases)
-STRK_HD constexpr bool band_class_lmax(int c) { return c >= 1; }
+// narrowest ones, where the bound on those alignments never reaches a good read's score (motifs of up to ~9 bases)
+STRK_HD constexpr bool band_class_lmax(int c) { return c >= 1 && c <= 3; }
 constexpr int kBandMaxFlank = 127;
 constexpr int kBandRowSlack = 96;    // prefix rows a band item may have beyond |db|
+constexpr int kBandNarrowSlack = 22; // diagonals the narrow class keeps free on each side of the candidates' span
 
 STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, int32_t lo, int32_t n) {
-    BandGeo b = {0, 0, 0, 0, 0, 0, 0, 0};
+    BandGeo b = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t ndb = (int64_t)nfl + ntr + nfr;
     if (nfl < 1 || nfr < 1 || nfr > kBandMaxFlank || m < 1 || m > 256 || n < 1 || n > 32) return b;
     const int64_t e_lo = (int64_t)ntr - (int64_t)(lo + n - 1) * m, e_hi = (int64_t)ntr - (int64_t)lo * m;
@@ -155,28 +165,33 @@ STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, 
     // (long motifs, BASELINE config 4) at a few per cent
     int64_t smin = ndb >> 5;
     if (smin < 12) smin = 12;
-    const int64_t need = span_hi - span_lo + 1 + 2 * smin;
     const int64_t rows = (int64_t)nfl + (int64_t)(lo + n - 1) * m;
     int32_t cls = -1;
-    for (int32_t c = 0; c < kNumBandClasses && cls < 0; ++c) {   // narrowest class that holds band and window
-        const int64_t w = 128 << c;
-        if (need > w) continue;
+    for (int32_t k = 0; k < kNumBandClasses && cls < 0; ++k) {   // narrowest class that holds band and window
+        const int32_t c = k == 0 ? kBandNarrowClass : k - 1;
+#ifdef STRK_NO_NARROW
+        if (c == kBandNarrowClass) continue;
+#endif
+        const int64_t w = band_class_wd(c);
+        const int64_t slack = (c == kBandNarrowClass && smin < kBandNarrowSlack) ? kBandNarrowSlack : smin;
+        if (span_hi - span_lo + 1 + 2 * slack > w) continue;
         if (ndb > band_max_db(c) || (int64_t)(n - 1) * m + w > band_max_col(c) || rows > band_max_db(c) + kBandRowSlack) continue;
         if (band_class_fly(c) && nfl > 255) continue;
         cls = c;
     }
     if (cls < 0) return b;
-    const int32_t wd = 128 << cls;
+    const int32_t wd = band_class_wd(cls);
     // (a band wider than the window covers the whole matrix: such short windows cost no more here than in the exact
     // kernel and spare it a launch that only a handful of reads would use)
-    if (cls > 0 && (int64_t)wd * 5 > (ndb + 1) * 4) return b;   // a wide band must drop at least a fifth of the columns
+    if (cls >= 1 && cls <= 3 && (int64_t)wd * 5 > (ndb + 1) * 4) return b;   // a wide band must drop at least a fifth of the columns
     const int64_t extra = wd - (span_hi - span_lo + 1);
     b.ok = 1;
     b.cls = cls;
-    b.G = 8 << cls;
+    b.G = band_class_G(cls);
     b.wd = wd;
     b.dlo = (int32_t)(span_lo - extra / 2);
-    b.bdlo = -(wd / 2);
+    b.bwd = wd;
+    b.bdlo = -(b.bwd / 2);
     b.cmin = (int32_t)(nfl + (int64_t)lo * m + b.dlo);
     b.ncol = (int32_t)((int64_t)(n - 1) * m + wd);
     return b;
@@ -200,7 +215,7 @@ STRK_HD int32_t band_ub(const BandGeo& b, int32_t nfl, int32_t ntr, int32_t nfr,
     if (v > L) L = v;
     v = band_len_beyond_hi(nc, ndb, e - b.bdlo + 1);                          // backward band, original diagonals
     if (v > L) L = v;
-    v = band_len_beyond_lo(nc, ndb, e - (b.bdlo + b.wd - 1) - 1);
+    v = band_len_beyond_lo(nc, ndb, e - (b.bdlo + b.bwd - 1) - 1);
     if (v > L) L = v;
     // alignments that end in the last column at a row <= R_i (free candidate end): the classes of band_class_lmax track
     // the in-band ones exactly (the rest leaves the band: first term), the narrowest class bounds them all

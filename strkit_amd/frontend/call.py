@@ -48,6 +48,9 @@ class CallOptions:
 
 
 MAX_READS = 250                 # params.max_reads default (strkit/call/params.py:21)
+RESIDENT_FACTOR = 7.5           # device bytes per byte of a BGZF alignment file kept whole in HBM: the compressed bytes + ~6x
+                                # decompressed (measured 5.8x on 30x HiFi data) + scan / extraction work buffers
+STRK_E_NOMEM = -12
 DEFAULT_REF_MAX_ITERS = 250     # call_locus.py:71 default_ref_max_iters (100 there is only the "slow" warning level, :72)
 VCF_ANCHOR_SIZE = 5             # params.vcf_anchor_size default
 
@@ -233,11 +236,12 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
                 tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL, front_end: str = "auto",
                 span_bytes: int = 4 << 30) -> dict:
     """`front_end` (for a `bam` given as a path): "device" = the file is inflated, scanned and cut on the GPU (DeviceBam) —
-    whole when it is below 24 GB (its decompressed form, about six times the file, stays in device memory next to the
-    workspace), else, with a .bai, in spans of at most `span_bytes` compressed bytes that follow the catalog; "host" =
-    block-wise through the .bai on the host cores (IndexedBam) or, without an index, the whole stream (NativeBam); "auto" =
-    "device" (a file of 24 GB or more needs its index for that), else "host".  Under torch.distributed every rank opens the
-    file on its own GPU and calls its share of the blocks."""
+    whole when the compressed bytes plus their decompressed form (taken as `RESIDENT_FACTOR` times the file) fit into 90 % of
+    the device memory that is free right now, else, with a .bai, in spans of at most `span_bytes` compressed bytes that follow
+    the catalog; "host" = block-wise through the .bai on the host cores (IndexedBam) or, without an index, the whole stream
+    (NativeBam); "auto" = "device" where that is possible, else "host".  A device reader that runs out of memory all the same
+    (a file that inflates more than expected) is retried in spans when the file has an index and replaced by the host reader
+    when it has none.  Under torch.distributed every rank opens the file on its own GPU and calls its share of the blocks."""
     t_open = time.perf_counter()
     own_reader = isinstance(bam, str)
     if isinstance(bam, str):
@@ -245,10 +249,14 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
         if front_end not in ("auto", "device", "host"):
             raise ValueError("front_end must be auto, device or host")
         has_index = os.path.exists(bam + ".bai") or os.path.exists(os.path.splitext(bam)[0] + ".bai")
-        small = os.path.getsize(bam) < (24 << 30)               # decompressed (about six times that) it fits in HBM
+        # (the device of the rank, as _lib.default_context picks it — or the caller's context's: one process per GPU)
+        dev = ctx.device if ctx is not None else int(os.environ.get("STRKIT_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        try:
+            free_mem = _lib.device_mem(dev)[0]
+        except Exception:  # noqa: BLE001  (no device: the reader below reports it)
+            free_mem = 0
+        small = os.path.getsize(bam) * RESIDENT_FACTOR < 0.9 * free_mem    # compressed + decompressed bytes stay in HBM
         use_device = front_end == "device" or (front_end == "auto" and (small or has_index))
-        # (the device of the rank, as _lib.default_context picks it: one process per GPU)
-        dev = int(os.environ.get("STRKIT_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         if use_device:                                            # a larger file goes through HBM span by span (needs the index)
             # The file is opened (read, uploaded, inflated, scanned: reader threads and the GPU, no Python) while this thread
             # loads the catalog and computes the reference side of every locus, which needs neither.  What both need — the
@@ -260,7 +268,18 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
             def open_reader():
                 t_ = time.perf_counter()
                 try:
-                    opened.append(DeviceBam(path, device=dev, span_bytes=None if small or not has_index else span_bytes))
+                    whole = small or not has_index
+                    try:
+                        opened.append(DeviceBam(path, device=dev, span_bytes=None if whole else span_bytes))
+                    except _lib.StrkError as e:
+                        if e.code != STRK_E_NOMEM:
+                            raise
+                        # it did not fit after all (a file that inflates more than RESIDENT_FACTOR says): the whole file goes
+                        # through HBM in spans when it has an index; without one, or when even a span fails, the host reader
+                        if whole and has_index:
+                            opened.append(DeviceBam(path, device=dev, span_bytes=span_bytes))
+                        else:
+                            opened.append(IndexedBam(path) if has_index else NativeBam(path))
                 except BaseException as e:  # noqa: BLE001  (handed to the caller's thread below)
                     opened.append(e)
                 opened.append(time.perf_counter() - t_)

@@ -20,7 +20,7 @@ from . import _lib
 from .segment import calculate_seq_with_wildcards
 
 __all__ = ["realign_read", "perform_realign", "realign_reads", "realign_pairs", "get_aligned_pair_matches",
-           "AlignedCoords", "cigar_to_string"]
+           "AlignedCoords", "cigar_to_string", "i16_saturation_flags"]
 
 match_score: int = 2                     # strkit/call/align_matrix.py:15
 min_realign_score_ratio: float = 0.95    # realign.py:28
@@ -115,17 +115,36 @@ def realign_pairs(ref_seqs: Sequence[str | bytes], query_seqs: Sequence[str | by
     return (out, st.as_dict()) if with_stats else out
 
 
+def i16_saturation_flags(ref_seqs: Sequence[str | bytes], query_seqs: Sequence[str | bytes], scores: Sequence[int]) -> np.ndarray:
+    """What the reference's fixed 16-bit parasail kernel (``sg_dx_trace_scan_16``, realign.py:56) would have done with these
+    pairs — ``strk_realign`` computes in 32 bits and never saturates: per pair 0, ``STRK_I16_CELL_MAY_SATURATE`` (an
+    intermediate cell can reach the 16-bit limit; the score itself fits) or that ``| STRK_I16_SCORE_SATURATES`` (the score
+    does not fit: the reference would compare a saturated result with its threshold)."""
+    n = len(scores)
+    o1 = np.zeros(n + 1, np.int64)
+    o2 = np.zeros(n + 1, np.int64)
+    np.cumsum([len(x) for x in ref_seqs], out=o1[1:])
+    np.cumsum([len(x) for x in query_seqs], out=o2[1:])
+    sc = np.ascontiguousarray(scores, np.int32)
+    out = np.zeros(max(n, 1), np.int32)
+    _lib.check(_lib.load().strk_realign_i16_flags(n, o1.ctypes.data, o2.ctypes.data, sc.ctypes.data, out.ctypes.data))
+    return out[:n]
+
+
 def _gate(flank_size: int) -> float:
     return min_realign_score_ratio * (flank_size * 2 * match_score - realign_indel_open_penalty)   # realign.py:65
 
 
 def realign_reads(ref_seqs: Sequence[str], query_seqs: Sequence[str], left_flank_coords: Sequence[int], flank_size: int,
                   context: _lib.Context | None = None) -> list[AlignedCoords | None]:
-    """``realign_read`` for many (reference window, wildcarded read) pairs in one device call."""
+    """``realign_read`` for many (reference window, wildcarded read) pairs in one device call.  A pair whose score does
+    not fit 16 bits (a window of more than 16 kb) is left un-realigned: the reference's 16-bit kernel would saturate there
+    and what it then compares with the threshold is not defined by the tree (``i16_saturation_flags``)."""
     res = realign_pairs(ref_seqs, query_seqs, context=context)
     th = _gate(flank_size)
-    return [None if sc < th else get_aligned_pair_matches(cg, int(lfc), 0, swap=True)
-            for (sc, _, cg), lfc in zip(res, left_flank_coords)]
+    sat = i16_saturation_flags(ref_seqs, query_seqs, [sc for sc, _, _ in res]) if res else []
+    return [None if (sc < th or (f & _lib.STRK_I16_SCORE_SATURATES)) else get_aligned_pair_matches(cg, int(lfc), 0, swap=True)
+            for (sc, _, cg), lfc, f in zip(res, left_flank_coords, sat)]
 
 
 def realign_read(ref_seq: str, query_seq: str, left_flank_coord: int, flank_size: int, q=None, read_log_str: str = "",

@@ -188,3 +188,76 @@ def test_band_kernel_under_every_end_flag_mode(gpu_ctx, flags):
             assert st["n_band_fallback"] <= st["n_band_reads"] // 3, st
     finally:
         ctx.close()
+
+
+def test_host_buffer_entry_point_is_pipelined_and_equal(monkeypatch):
+    """strk_count_loci on host buffers cuts a large batch into sub-batches of whole loci that travel through three pinned
+    slots (strk_host_pipe.inc): same answers as the oracle and as the one-piece path, empty loci and a window-miss round
+    inside a sub-batch included; the statistics of the sub-batches add up."""
+    from strkit_amd import _lib
+    monkeypatch.setenv("STRKIT_AMD_PIPE_MB", "1")           # sub-batches of ~1 MB: a dozen of them for this batch
+    b = LocusBatch.concat([make_config(2, n_loci=700, seed_shift=5), make_config(3, n_loci=40, seed_shift=6),
+                           make_config(2, n_loci=600, seed_shift=7)])
+    rng = np.random.default_rng(5)
+    b.est_cn = b.est_cn.copy()
+    b.est_cn[rng.integers(0, b.n_reads, size=30)] += 11        # bad estimates: some searches leave their window
+    exp = oracle_count(b)
+    ctx = _lib.Context(0)
+    try:
+        got, st = _run(b, ctx)
+        _compare(b, got, exp)
+        assert st["n_dp_launches"] >= 6, st                   # sub-batches
+        assert st["n_band_reads"] + st["n_dedup_reads"] > b.n_reads // 2 and st["kernel_ms"] > 0
+        monkeypatch.setenv("STRKIT_AMD_PIPE_MB", "4096")     # too small to cut up: the direct path
+        got1, st1 = _run(b, ctx)
+        _compare(b, got1, exp)
+        assert st1["n_dp_launches"] == 2
+    finally:
+        ctx.close()
+
+
+def test_narrow_band_class_takes_short_motifs(gpu_ctx):
+    """Motifs of up to four bases run in the 96-diagonal class (8 lanes x 12 diagonals), longer ones in the 128-diagonal
+    class; both certify HiFi-like reads and agree with the oracle (strk_search.h: band_geometry)."""
+    rng = np.random.default_rng(77)
+    for mlen in ((2, 4), (5, 6)):
+        loci = [random_locus(rng, 12, motif_len=mlen, cn=(8, 50), flank=(70, 70), edits=(0, 2)) for _ in range(60)]
+        b = LocusBatch.from_reads(loci)
+        from strkit_amd import _lib
+        ctx = _lib.Context(0)
+        try:
+            got, st = _run(b, ctx, window=6)
+            _compare(b, got, oracle_count(b))
+            assert st["n_band_reads"] >= b.n_reads // 3 and st["n_band_fallback"] <= st["n_band_reads"] // 5, st
+        finally:
+            ctx.close()
+
+
+def test_staircase_fork_rows_in_the_wide_exact_classes(gpu_ctx):
+    """Windows of 449 bases and more run with 32 / 64 lanes per read and fold their fork rows along a staircase
+    (strk_dp_exact.h); items whose smallest candidate has fewer motif rows than lanes take the per-lane fold, alone or in
+    one chunk with others.  Noisy reads, long and short motifs, every end-flag family that the fold touches."""
+    rng = np.random.default_rng(78)
+    loci = []
+    for k in range(36):
+        mlen = (2, 6) if k % 3 == 0 else ((7, 13) if k % 3 == 1 else (14, 20))
+        hi = 1500 // mlen[1]
+        loci.append(random_locus(rng, 4, motif_len=mlen, cn=(320 // mlen[0], max(330 // mlen[0], hi)), flank=(30, 70), edits=(0, 40), alpha=ALPHA_WC))
+    loci.append(random_locus(rng, 4, motif_len=(19, 20), cn=(16, 18), flank=(70, 70), edits=(0, 6)))   # window reaches candidate 1
+    b = LocusBatch.from_reads(loci)
+    for flags, fb in ((15, True), (0, False), (5, True), (10, True)):
+        got, st = _run(b, gpu_ctx, band=False, end_flags=flags, feedback=fb, window=15)
+        _compare(b, got, oracle_count(b, flags=flags, feedback=fb))
+        assert st["n_fallback"] == 0
+
+
+def test_unknown_narrowing_schedule_is_rejected(gpu_ctx):
+    from strkit_amd import _lib
+    from strkit_amd.batch import batch_struct, make_params
+    import ctypes as C
+    b = make_config(2, n_loci=3)
+    s, keep = batch_struct(b)
+    p = make_params(narrowing=1)
+    outs = [np.zeros(b.n_reads, np.int32) for _ in range(4)]
+    rc = _lib.load().strk_count_loci(gpu_ctx.handle, C.byref(s), C.byref(p), *[o.ctypes.data for o in outs], None)
+    assert rc == -22 and b"narrowing" in _lib.load().strk_last_error()

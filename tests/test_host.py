@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "strkit_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(strk_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(strk_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_builds_loads_and_exports_every_declared_symbol():
@@ -57,7 +57,7 @@ def test_init_fails_loudly_without_a_gpu_and_errors_are_reported():
 
 def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.StrkParams) == 40
-    assert C.sizeof(_lib.StrkStats) == 72
+    assert C.sizeof(_lib.StrkStats) == 112
     assert C.sizeof(_lib.StrkBatch) == 8 + 9 * 8
 
 
@@ -317,3 +317,16 @@ def test_bench_strong_staging_layout_over_two_ranks():
             t = np.array(got[rank][j], np.int32)
             assert np.array_equal(t[0], exp["cn"]) and np.array_equal(t[1], exp["score"])
             assert np.array_equal(t[2], exp["n_iters"] + j) and np.array_equal(t[3], exp["start"])
+
+
+def test_realign_i16_saturation_flags():
+    """What parasail's fixed 16-bit kernel (realign.py:56) would have done: flags from lengths and 32-bit scores."""
+    lib = _lib.load(build=False)
+    s1 = np.array([0, 400, 400 + 16383, 400 + 16383 + 17000, 400 + 16383 + 17000 + 20000], np.int64)
+    s2 = np.array([0, 15000, 40000, 70000, 70010], np.int64)      # the last read is 10 bases long
+    score = np.array([790, 32000, 32766, 12], np.int32)
+    out = np.full(4, -1, np.int32)
+    assert lib.strk_realign_i16_flags(4, s1.ctypes.data, s2.ctypes.data, score.ctypes.data, out.ctypes.data) == 0
+    assert out.tolist() == [0, _lib.STRK_I16_CELL_MAY_SATURATE,
+                            _lib.STRK_I16_CELL_MAY_SATURATE | _lib.STRK_I16_SCORE_SATURATES, 0]
+    assert lib.strk_realign_i16_flags(1, None, s2.ctypes.data, score.ctypes.data, out.ctypes.data) == -22

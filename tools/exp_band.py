@@ -26,7 +26,7 @@ for i in range(14):
     L.strk_count_loci(ctx.handle, C.byref(s), C.byref(p), *[o.ctypes.data for o in outs], C.byref(st))
     if i >= 10: tb.append(st.band_kernel_ms); td.append(st.dp_kernel_ms); tk.append(st.kernel_ms)
 h = hashlib.sha1(b"".join(o.tobytes() for o in outs)).hexdigest()[:12]
-print("band %.4f ms  exact %.4f ms  all %.4f ms  band_reads %d fb %d win %d  sha %s" % (sum(tb)/len(tb), sum(td)/len(td), sum(tk)/len(tk), st.n_band_reads, st.n_band_fallback, st.window_used, h))
+print("band %.4f ms  exact %.4f ms  all %.4f ms  (head %.3f wide %.3f long %.3f generic %.3f replay %.3f)  band_reads %d fb %d win %d  cells %.3g  sha %s" % (sum(tb)/len(tb), sum(td)/len(td), sum(tk)/len(tk), st.head_ms, st.band_wide_kernel_ms, st.long_kernel_ms, st.generic_kernel_ms, st.replay_ms, st.n_band_reads, st.n_band_fallback, st.window_used, st.dp_cells, h))
 '''
 
 
@@ -38,14 +38,21 @@ def main():
         i = args.index("--config"); cfg = int(args[i + 1]); del args[i:i + 2]
     if "--bench" in args:
         bench = True; args.remove("--bench")
+    dbgs = []          # extra runs of the product library with STRKIT_AMD_DBG set (e.g. 32: no staircase fork rows)
+    while "--dbg" in args:
+        i = args.index("--dbg"); dbgs.append(args[i + 1]); del args[i:i + 2]
     libs = {"product": os.path.join(ROOT, "strkit_amd", "lib", "libstrkit_amd.so")}
     for p in sorted(glob.glob(os.path.join(ROOT, "strkit_amd", "lib", "exp", "*.so"))):
         libs[os.path.basename(p)[:-3]] = p
     if args:
         libs = {k: v for k, v in libs.items() if k in args or k == "product"}
     nb = {2: 10, 3: 10, 4: 10, 5: 1}.get(cfg, 10)
-    for name, path in libs.items():
-        env = dict(os.environ, STRKIT_AMD_LIB=path)
+    runs = [(name, path, None) for name, path in libs.items()] + [(f"product dbg={d}", libs["product"], d) for d in dbgs]
+    for name, path, dbg in runs:
+        env = dict(os.environ, STRKIT_AMD_LIB=path, STRKIT_AMD_NO_PIPE="1")   # (one call = one launch of every kernel)
+        if dbg is not None:
+            env["STRKIT_AMD_DBG"] = dbg
+        print(f"# {name} ...", flush=True)
         out = subprocess.run([sys.executable, "-c", CODE, str(cfg), str(nb)], env=env, capture_output=True, text=True, cwd=ROOT)
         line = out.stdout.strip() or out.stderr.strip()[-300:]
         print(f"{name:16s} {line}", flush=True)
@@ -54,7 +61,9 @@ def main():
                                   "--config", str(cfg)], env=env, capture_output=True, text=True, cwd=ROOT)
             try:
                 j = json.loads(out.stdout.strip().splitlines()[-1])
-                print(f"{name:16s} bench {j['value'] / 1e6:.1f} M reads/s  ms/step {j['ms_per_step']:.4f}  parity {j['parity_check']}  fb/step {j['band_fallback_per_step']}", flush=True)
+                print(f"{name:16s} bench {j['value'] / 1e6:.1f} M reads/s  ms/step {j['ms_per_step']:.4f}  parity {j['parity_check']}  fb/step {j['band_fallback_per_step']}"
+                      f"  miss/step {j['window_miss_reads_per_step']}  window {j['config']['window']}  device_ms/step {j['device_ms_per_step']:.3f}"
+                      f"  band_reads/step {j['band_reads_per_step']:.0f}  k_ms {j['roofline'].get('kernel_ms_overlapped', 0):.3f}", flush=True)
             except Exception as e:  # noqa: BLE001
                 print(f"{name:16s} bench failed: {e} {out.stderr[-300:]}", flush=True)
 
