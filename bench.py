@@ -248,7 +248,9 @@ def main() -> None:
     ap.add_argument("--no-dedupe", action="store_true", help="score identical reads of a locus separately")
     ap.add_argument("--no-band", action="store_true", help="exact kernels only (no banded first pass)")
     ap.add_argument("--gather-every", type=int, default=4, help="steps per result all-gather when several ranks run")
-    ap.add_argument("--pipeline", type=int, default=3, help="batched calls in flight (contexts/streams); tools/grid_sweep.sh: 185 M reads/s at 2, 206 M at 3, 172 M at 4")
+    ap.add_argument("--pipeline", type=int, default=2, help="batched calls in flight (contexts/streams): with two, the band kernel of one call and "
+                    "everything else of the other share the device and the persistent band blocks of a THIRD call never hold the LDS that the small "
+                    "kernels behind a band pass wait for (profiles/README.md round 3: 221 M reads/s at 2, 174 M at 3, 198 M at 4-6)")
     ap.add_argument("--cpu-sample-loci", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the pipeline-1 and host-buffer (PCIe-inclusive) sub-results")
@@ -548,10 +550,14 @@ def main() -> None:
     for c in sorted(sub_batches):
         progress(f"extras: config {c}")
         bl_c = sub_batches[c]
+        # contexts of its own: the band of a shared context may be in a cool-down after another configuration's noisy reads
+        for cx in ctxs:
+            cx.close()
+        ctxs = [_lib.Context(local_rank) for _ in range(D)]
         res_c = [resident(b) for b in bl_c]
         rows_c = max(b.n_reads for b in bl_c)
         out_c = torch.zeros((D + 1, NF, rows_c), dtype=torch.int32, device=dev)
-        n_prime = 6 if c != 3 else 10          # band probation, window level, history-sized grids settle
+        n_prime = 12                           # band probation, window level, history-sized grids settle
         for i in range(n_prime):
             _lib.check(L.strk_count_loci_device(ctxs[i % D].handle, C.byref(res_c[i % 2][1]), C.byref(p), out_c[0, 1].data_ptr(),
                                                 out_c[0, 2].data_ptr(), out_c[0, 3].data_ptr(), out_c[0, 4].data_ptr(),

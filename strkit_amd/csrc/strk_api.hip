@@ -45,6 +45,7 @@ extern "C" int strk_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8
 namespace {
 
 thread_local std::string g_err;
+constexpr int kWinStartLevel = 1, kWinLevels = 4;   // kWindowLevels below: a process starts at 8 sizes either side of the estimate
 struct HostPipe;   // strk_host_pipe.inc: the pinned-slot pipeline behind strk_count_loci
 
 // batched calls submitted and not yet finished, over all contexts of this process: a call that will share the
@@ -58,7 +59,7 @@ std::atomic<int> g_calls_in_flight{0};
 // a level down.
 // One level per motif-length bucket (win_bucket): the estimate round(|tr| / |motif|) is off by the read's indel drift divided
 // by the motif length, so the reads of long motifs stay inside narrow windows that those of short ones leave.
-std::atomic<int> g_win_level[4] = {{1}, {1}, {1}, {1}};
+std::atomic<int> g_win_level[4] = {{kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}};
 std::atomic<int> g_win_quiet[4] = {{0}, {0}, {0}, {0}};
 
 // CPUs this process may run on (a container's share, not the machine's core count)
@@ -126,9 +127,10 @@ struct strk_ctx {
     // realignment (strk_realign)
     DevBuf rl_s1, rl_s2, rl_pairs, rl_trace, rl_edge, rl_out, rl_cigar, rl_queue;
     int32_t* h_counters = nullptr;  // pinned: counters + cells + scratch_used
-    // a chain of events along one call: start | after k_hash + k_plan | after k_dp_band | after k_dp_band_wide | after
-    // k_dp_all / k_dp_ref | after k_dp_long | after k_dp_generic | end (after k_replay and the counters' copy)
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // a chain of events along one call: start | after k_hash + k_plan | after k_dp_band | after k_dp_band_wide | after the
+    // first k_replay pass | after k_dp_all / k_dp_ref | after k_dp_long | after k_dp_generic | end (after k_replay and the
+    // counters' copy)
+    hipEvent_t ev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_ints = 0;
     int band_cooldown = 0;   // > 0: the band kernel is switched off for that many calls (too many certificates failed)
     int band_penalty = 32;   // length of the next cool-down (doubles while retries keep failing)
@@ -155,9 +157,12 @@ namespace {
 using namespace strk;
 
 constexpr int kDefaultWindow = 8;
-enum { kEvStart = 0, kEvHead, kEvBand, kEvWide, kEvExact, kEvLong, kEvGeneric, kEvEnd, kNumEvents };
+enum { kEvStart = 0, kEvHead, kEvBand, kEvWide, kEvPre, kEvExact, kEvLong, kEvGeneric, kEvEnd, kNumEvents };
 constexpr int kBandProbationReads = 2048;
-constexpr int kWindowLevels[4] = {6, 8, 11, 15};   // default half-widths of the candidate window, see g_win_level
+// default half-widths of the candidate window, see g_win_level.  (5 was tried as the narrowest level: the search from a start
+// the feedback moved by one size then ends at the window's edge, 780 reads per 10 000-locus call turn out uncertain and one or
+// two leave the window: 205 M reads/s instead of 221 M.)
+constexpr int kWindowLevels[kWinLevels] = {6, 8, 11, 15};
 // Scratch pool (int32 units): kLongWaves slots of kLongSlotInts for k_dp_long (one per resident wave; a slot
 // holds the backward row of all column tiles + two boundary columns: windows up to ~16 kb), then 16 Mi
 // ints of H rows for the generic kernel.  448 MiB of the 288 GB, allocated once per context.
@@ -196,7 +201,7 @@ int ensure_workspace(strk_ctx* c, int n_reads, int n_loci, size_t table_ints, si
     if ((rc = c->cls_list.ensure((size_t)kNumLists * std::max<size_t>(n_items, 1) * 2 * 4))) return rc;
     if ((rc = c->band_recs.ensure((size_t)kNumBandClasses * std::max<size_t>(n_items, 1) * 3 * sizeof(int4)))) return rc;
     if ((rc = c->counters.ensure(kCountersBytes))) return rc;
-    if ((rc = c->state_i32.ensure(nl * 3 * 4))) return rc;
+    if ((rc = c->state_i32.ensure(nl * 4 * 4))) return rc;
     if ((rc = c->state_f64.ensure(nl * 8))) return rc;
     if ((rc = c->spec.ensure(nr * 16))) return rc;
     if ((rc = c->rhash.ensure(nr * 8))) return rc;
@@ -252,7 +257,7 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
 
 // plan (classification) + all DP kernels for the reads in `items` (NULL = all reads).
 void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_items, int n_items, int force_generic,
-                     hipStream_t st, bool time_dp) {
+                     hipStream_t st, bool time_dp, const ReplayArgs* pre_replay = nullptr) {
     hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, a, mode, d_items, n_items, force_generic);
     static const int tune = getenv("STRKIT_AMD_DP_BLOCKS") ? atoi(getenv("STRKIT_AMD_DP_BLOCKS")) : 0;   // tuning aid
     // a call that shares the device with other calls in flight takes seven eighths of the CU slots per kernel, so
@@ -280,9 +285,10 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     }
     if (time_dp) (void)hipEventRecord(c->ev[kEvBand], st);
     if (band) hipLaunchKernelGGL(k_dp_band_wide, dim3(predicted_blocks(c->hist_wide_chunks, band_blocks)), dim3(256), 0, st, a);   // long windows
-#ifndef STRK_FEW_EVENTS
     if (time_dp) (void)hipEventRecord(c->ev[kEvWide], st);
-#endif
+    // first k_replay pass (strk_replay.h): as far as the certified band tables carry each locus, before the exact kernels
+    if (band && pre_replay) hipLaunchKernelGGL(k_replay, dim3(a.n_loci), dim3(64), 0, st, a, *pre_replay);
+    if (time_dp) (void)hipEventRecord(c->ev[kEvPre], st);
     if (!force_generic) {
         // persistent-style grid: every wave pulls chunks from the device-side queue until it is empty
         constexpr int kBlocksPerCU = std::max(1, std::min(8, (160 * 1024) / (4 * kWaveLdsBytes + kLdsSlack + 1024)));
@@ -292,15 +298,12 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
         else hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);
     }
     if (time_dp) (void)hipEventRecord(c->ev[kEvExact], st);
-    if (!force_generic && !a.ref_mode)
-        hipLaunchKernelGGL(k_dp_long, dim3(predicted_blocks(c->hist_long, kLongBlocks)), dim3(256), 0, st, a);
-#ifndef STRK_FEW_EVENTS
+    if (!force_generic && !a.ref_mode)   // (a window-miss round or an explicit table: never more blocks than items)
+        hipLaunchKernelGGL(k_dp_long, dim3(mode == 0 ? predicted_blocks(c->hist_long, kLongBlocks) : std::max(1, std::min(kLongBlocks, a.list_stride))),
+                           dim3(256), 0, st, a);
     if (time_dp) (void)hipEventRecord(c->ev[kEvLong], st);
-#endif
     hipLaunchKernelGGL(k_dp_generic, dim3(256), dim3(256), 0, st, a);
-#ifndef STRK_FEW_EVENTS
     if (time_dp) (void)hipEventRecord(c->ev[kEvGeneric], st);
-#endif
 }
 
 int check_error_bits(int bits) {
@@ -326,8 +329,8 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     if (c->p_window_auto) {
         p.window = 0;
         for (int k = 0; k < 4; ++k) {
-            const int w = kWindowLevels[std::min(3, std::max(0, g_win_level[k].load(std::memory_order_relaxed)))];
-            c->p_window_b[k] = std::max(w, std::min(kWindowLevels[3], p.local_search_range + p.step_size + 2));
+            const int w = kWindowLevels[std::min(kWinLevels - 1, std::max(0, g_win_level[k].load(std::memory_order_relaxed)))];
+            c->p_window_b[k] = std::max(w, std::min(kWindowLevels[kWinLevels - 1], p.local_search_range + p.step_size + 2));
             p.window = std::max(p.window, c->p_window_b[k]);
         }
     }
@@ -351,7 +354,10 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     rp.next_read = c->state_i32.as<int32_t>();
     rp.need_lo = rp.next_read + b->n_loci;
     rp.need_hi = rp.need_lo + b->n_loci;
+    rp.stop = rp.need_hi + b->n_loci;
     rp.frac = c->state_f64.as<double>();
+    rp.resume = 0;
+    rp.pre_exact = 0;
 
     struct InFlight {   // counted before the launches (the grid size depends on it), un-counted on any early error return
         bool keep = false;
@@ -361,7 +367,10 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     HIP_TRY(hipEventRecord(c->ev[kEvStart], st));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
     if (a.rhash) hipLaunchKernelGGL(k_hash, dim3((b->n_reads + 31) / 32), dim3(256), 0, st, a);   // eight lanes per read
-    enqueue_scoring(c, a, 0, nullptr, b->n_reads, 0, st, true);
+    ReplayArgs rp_pre = rp;
+    rp_pre.pre_exact = 1;
+    enqueue_scoring(c, a, 0, nullptr, b->n_reads, 0, st, true, a.band_mode ? &rp_pre : nullptr);
+    rp.resume = a.band_mode ? 1 : 0;   // band calls: the second pass, behind the exact kernels (strk_replay.h)
     hipLaunchKernelGGL(k_replay, dim3(b->n_loci), dim3(64), 0, st, a, rp);
     HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(c->ev[kEvEnd], st));
@@ -393,10 +402,10 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         stats->head_ms = span(kEvStart, kEvHead);
         stats->band_kernel_ms = span(kEvHead, kEvBand);
         stats->band_wide_kernel_ms = span(kEvBand, kEvWide);
-        stats->dp_kernel_ms = span(kEvWide, kEvExact);
+        stats->dp_kernel_ms = span(kEvPre, kEvExact);
         stats->long_kernel_ms = span(kEvExact, kEvLong);
         stats->generic_kernel_ms = span(kEvLong, kEvGeneric);
-        stats->replay_ms = span(kEvGeneric, kEvEnd);
+        stats->replay_ms = span(kEvGeneric, kEvEnd) + span(kEvWide, kEvPre);   // both k_replay passes
         {
             const unsigned long long* u = reinterpret_cast<const unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
             stats->band_bytes = (int64_t)u[2];
@@ -407,6 +416,12 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         stats->n_long_reads = c->h_counters[kCntClass0 + kLongClass];
         stats->n_dp_launches = 2;
         stats->window_used = c->p_params.window;
+        if (c->p_window_auto) {   // the widest default window among the motif-length buckets that had loci in this call
+            int w = 0;
+            for (int k = 0; k < 4; ++k)
+                if (c->h_counters[kCntLociB + k] > 0) w = std::max(w, c->p_window_b[k]);
+            if (w > 0) stats->window_used = w;
+        }
         stats->n_fallback = c->h_counters[kCntClass0 + kGenericClass];
         stats->n_dedup_reads = c->h_counters[kCntDup];
         stats->n_band_reads = 0;
@@ -430,7 +445,7 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
             const int level = g_win_level[k].load(std::memory_order_relaxed);
             // a handful of misses costs less (one short extra round) than a wider window for every read does
             if (n_miss > std::max(2, n_loci_k / 250)) {
-                if (level < 3) g_win_level[k].store(level + 1, std::memory_order_relaxed);
+                if (level < kWinLevels - 1) g_win_level[k].store(level + 1, std::memory_order_relaxed);
                 g_win_quiet[k].store(level == 0 ? -56 : 0, std::memory_order_relaxed);   // a failed narrow window is not retried soon
             } else if (n_miss > std::max(1, n_loci_k / 1000)) {   // more than one locus in a thousand: not a quiet call
                 g_win_quiet[k].store(0, std::memory_order_relaxed);
@@ -597,7 +612,7 @@ int score_table_impl(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, 
     if (stats) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ctx->ev[kEvStart], ctx->ev[kEvEnd]) == hipSuccess) stats->kernel_ms = ms;
-        if (hipEventElapsedTime(&ms, ctx->ev[kEvWide], ctx->ev[kEvExact]) == hipSuccess) stats->dp_kernel_ms = ms;
+        if (hipEventElapsedTime(&ms, ctx->ev[kEvPre], ctx->ev[kEvExact]) == hipSuccess) stats->dp_kernel_ms = ms;
         stats->n_dp_launches = 2;
         stats->n_fallback = ctx->h_counters[kCntClass0 + kGenericClass];
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->h_counters) + kCellsOff);
@@ -665,6 +680,7 @@ void strk_destroy(strk_ctx* c) {
     c->pipe = nullptr;
     DevBuf* bufs[] = {&c->read_locus, &c->win_lo, &c->win_n, &c->tab_off, &c->table, &c->cls_list, &c->band_recs, &c->counters,
                       &c->scratch, &c->state_i32, &c->state_f64, &c->spec, &c->rhash, &c->rep, &c->exact, &c->win_lo2, &c->win_n2, &c->tab_off2, &c->table2,
+
                       &c->items, &c->in_seqs, &c->in_seq_off, &c->in_nfl, &c->in_ntr, &c->in_nfr, &c->in_est,
                       &c->in_read_off, &c->in_motifs, &c->in_motif_off, &c->out_cn, &c->out_score, &c->out_n,
                       &c->out_start, &c->rl_s1, &c->rl_s2, &c->rl_pairs, &c->rl_trace, &c->rl_edge, &c->rl_out, &c->rl_cigar,

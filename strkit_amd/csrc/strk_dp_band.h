@@ -446,6 +446,11 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     if (run)
         for (int k = lig; k < n; k += G) ubA[k] = band_ub(geo, nfl, ntr, nfr, m, lo + k, a.end_flags);
     wave_lds_sync();
+    // The search is replayed with the certificate from the ESTIMATE only.  (Replaying it from the starts the caller's feedback
+    // can turn the estimate into — est +- 1, 2: five lanes, one start each — was tried so that k_replay would never meet an
+    // uncertain table: half of the HiFi reads then fail, because a search window that does not hold the best size has a
+    // maximum 5 |motif| to 7 |motif| per size below it, under the 2 * len(diagonal) bound of its inexact entries.  Reads that
+    // turn out uncertain from their real start are re-scored on the device instead: k_replay's append lists, strk_replay.h.)
     if (act && first) {
         bool certified = (a.dbg & 4) != 0;
         if (run && !(a.dbg & 4)) {

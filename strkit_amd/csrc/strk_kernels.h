@@ -215,6 +215,8 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     __shared__ int s_base[kNumLists];
     __shared__ unsigned long long s_cells, s_bytes_band, s_bytes_exact, s_bytes_wide, s_bytes_long;
     __shared__ unsigned long long s_key[256];
+    __shared__ int s_lb[4];   // loci per motif-length bucket (counted at a locus's first read)
+    if (threadIdx.x < 4) s_lb[threadIdx.x] = 0;
     if (threadIdx.x < kNumLists) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_cells = 0; s_bytes_band = 0; s_bytes_exact = 0; s_bytes_wide = 0; s_bytes_long = 0; }
     __syncthreads();
@@ -231,6 +233,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
         l = lo_l;
         a.read_locus[r] = l;
         m = a.motif_off[l + 1] - a.motif_off[l];
+        if (mode == 0 && r == a.read_off[l] && m >= 1) atomicAdd(&s_lb[win_bucket(m)], 1);
         nfl = a.nfl[r]; ntr = a.ntr[r]; nfr = a.nfr[r];
         if (m < 1 || nfl < 0 || ntr < 0 || nfr < 0) {
             atomicOr(&a.counters[kCntError], kErrBadInput);
@@ -304,6 +307,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
         s_base[c] = s_cnt[c] ? atomicAdd(&a.counters[kCntClass0 + c], s_cnt[c]) : 0;
         s_cnt[c] = 0;
     }
+    if (threadIdx.x < 4 && s_lb[threadIdx.x]) atomicAdd(&a.counters[kCntLociB + threadIdx.x], s_lb[threadIdx.x]);
     if (threadIdx.x == 0 && s_cells) {
         atomicAdd(a.cells, s_cells);
         if (s_bytes_band) atomicAdd(a.cells + 2, s_bytes_band);

@@ -19,7 +19,20 @@ struct ReplayArgs {
     double* frac;         // [n_loci]
     int32_t* need_lo;     // [n_loci] window wanted by the read that missed
     int32_t* need_hi;
+    // Two passes when the banded kernel took part (strk_api.hip: ... k_dp_band -> k_replay pass 1 -> exact kernels -> k_replay
+    // pass 2).  Pass 1 (pre_exact = 1) runs BEFORE the exact kernels: it walks every locus as far as certified band tables
+    // carry it.  At a read whose table is still to be written by the exact kernels (a band fall-back, a read the band never
+    // took) it notes where the locus stopped and leaves; at a read whose banded table cannot certify the search from the
+    // start the feedback gave it (the band kernel certified it from the estimate only) it first appends that read and every
+    // later read of the locus that still has a banded table to the exact kernels' class lists — reads of a locus look alike:
+    // what is uncertain for one usually is for the next.  Pass 2 (resume = 1) runs behind the exact kernels and takes the
+    // stopped loci from there with exact tables, so that the only misses left for the host are searches that leave their
+    // candidate window.  (Before: every uncertain read was a miss, and every call of the bench workload paid a host round.)
+    int32_t pre_exact;     // 1: pass 1
+    int32_t resume;        // 1: pass 2 — continue the loci with stop[l] == kStopRescore from next_read / frac
+    int32_t* stop;         // [n_loci] kStopNone / kStopRescore / kStopMiss
 };
+constexpr int kStopNone = 0, kStopRescore = 1, kStopMiss = 2;
 
 // One wave per locus: lane i holds the inputs of the locus's i-th read (coalesced loads), the
 // in-order chain over the reads is wave-uniform ALU work on values fetched with v_readlane.
@@ -31,8 +44,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
     const int r_end = a.read_off[l + 1];
     double frac = 0.0;
     int r_next = a.read_off[l];   // first read not finished yet
-    bool missed = false;
-    for (int base = r_next; base < r_end && !missed; base += 64) {
+    if (p.resume) {
+        if (p.stop[l] != kStopRescore) return;
+        r_next = p.next_read[l];
+        frac = p.frac[l];
+    }
+    bool missed = false, rescore = false;
+    for (int base = r_next; base < r_end && !missed && !rescore; base += 64) {
         const int cnt = min(64, r_end - base);
         const int rl = base + lane;
         const int my_est = lane < cnt ? a.est_cn[rl] : 0;
@@ -58,7 +76,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                 const int r = base + i;
                 const int rp = a.rep[r];
                 SeenMask64 seen;
-                if (!a.band_mode || a.exact[rp]) {
+                const bool is_exact = !a.band_mode || a.exact[rp];
+                if (p.pre_exact && is_exact) {   // its table comes with the exact kernels: pass 2 continues here
+                    rescore = true;
+                    break;
+                }
+                if (is_exact) {
                     res = search_replay(start, p.step, p.lsr, p.max_iters, p.tie_last, a.table + a.tab_off[r], a.win_lo[r],
                                         min(a.win_n[r], 64), seen);
                 } else {
@@ -72,6 +95,33 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                     const CertResult cr = search_replay_cert(start, p.step, p.lsr, p.max_iters, p.tie_last,
                                                              a.table + a.tab_off[r], wlo, wn, seen, ub);
                     res = cr.res;
+                    if (cr.uncertain && p.pre_exact) {
+                        // this read and the rest of the locus go to the exact kernels (every read at most once: test-and-set of
+                        // its flag byte), lane j taking read r + j, r + j + 64, ...
+                        for (int q0 = r; q0 < r_end; q0 += 64) {
+                            const int q = q0 + lane;
+                            if (q >= r_end) continue;
+                            const int rq = a.rep[q];
+                            unsigned* const w = reinterpret_cast<unsigned*>(a.exact + (rq & ~3));
+                            const unsigned bit = 1u << (8 * (rq & 3));
+                            if (atomicOr(w, bit) & (0xffu << (8 * (rq & 3)))) continue;   // exact already, or listed by another lane
+                            const int cls = classify(a.nfl[rq], a.ntr[rq], a.nfr[rq], m, a.win_lo[rq], min(a.win_n[rq], kTableMax), 0, 0);
+                            const int idx = atomicAdd(&a.counters[kCntClass0 + cls], 1);
+                            if (idx < a.list_stride) {
+                                int32_t* gl = a.cls_list + (size_t)cls * a.list_stride * 2;
+                                gl[2 * idx] = rq;
+                                gl[2 * idx + 1] = 0;
+                            } else {
+                                atomicOr(&a.counters[kCntError], kErrScratch);
+                            }
+                            atomicAdd(&a.counters[kCntBandFallback], 1);
+                            if (cls != kGenericClass)
+                                atomicAdd(a.cells, (unsigned long long)(a.nfl[rq] + a.ntr[rq] + a.nfr[rq]) *
+                                                       ((unsigned long long)a.nfl[rq] + (unsigned long long)(a.win_lo[rq] + a.win_n[rq] - 1) * m + a.nfr[rq]));
+                        }
+                        rescore = true;
+                        break;
+                    }
                     if (cr.uncertain) { res.miss = 1; res.need_lo = wlo; res.need_hi = wlo + wn - 1; }
                 }
             }
@@ -105,10 +155,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
     if (lane == 0) {
         p.next_read[l] = r_next;
         p.frac[l] = frac;
-        // per motif-length bucket: loci, and loci whose search left its window (the host adapts each bucket's default window)
-        const int bkt = win_bucket(a.motif_off[l + 1] - a.motif_off[l]);
-        atomicAdd(&a.counters[kCntLociB + bkt], 1);
-        if (missed) atomicAdd(&a.counters[kCntMissB + bkt], 1);
+        p.stop[l] = rescore ? kStopRescore : (missed ? kStopMiss : kStopNone);
+        // loci whose search left its window, per motif-length bucket (the host adapts each bucket's default window; k_plan
+        // counts the loci of a bucket)
+        if (missed) atomicAdd(&a.counters[kCntMissB + win_bucket(a.motif_off[l + 1] - a.motif_off[l])], 1);
     }
 }
 
