@@ -461,7 +461,8 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
             const int per = 64 / class_G(k);
             exact_chunks += (c->h_counters[kCntClass0 + k] + per - 1) / per;
         }
-        for (int k = 2; k <= 3; ++k) {   // the classes of k_dp_band_wide
+        for (int k = 0; k < kNumBandClasses; ++k) {   // the classes of k_dp_band_wide
+            if (!band_class_wide_kernel(k)) continue;
             const int per = 64 / band_class_G(k);
             wide_chunks += (c->h_counters[kCntClass0 + kBandClass0 + k] + per - 1) / per;
         }

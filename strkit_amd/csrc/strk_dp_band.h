@@ -35,8 +35,8 @@ struct BandLayout {
           group_bytes(off_b0 + ((band_max_col(c) * 2 + 15) & ~15)),
           sel_len((band_max_db(c) + 2 * ((128 << c) + (8 << c) + 8) + kBandHiPad) & ~3) {}
 };
-static_assert(band_class_layout(kBandNarrowClass) == 0 && band_class_wd(kBandNarrowClass) <= 128 && band_class_G(kBandNarrowClass) == 8,
-              "the narrow class uses class 0's LDS layout: pads sized for 128 diagonals and 8 lanes cover it");
+static_assert(band_class_layout(4) == 0 && band_class_layout(7) == 3 && band_class_wd(5) <= band_class_wd(1) && band_class_G(6) == band_class_G(2),
+              "a 12-diagonal class uses the LDS layout of the 16-diagonal class with its lane count: pads sized for the wider band cover it");
 __host__ __device__ constexpr int band_wave_lds(int c) { return (64 / (8 << c)) * BandLayout(c).group_bytes; }
 __host__ __device__ constexpr int max_band_wave_lds(int c) {
     return c < 0 ? 0 : (band_wave_lds(c) > max_band_wave_lds(c - 1) ? band_wave_lds(c) : max_band_wave_lds(c - 1));
@@ -483,18 +483,19 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     STRK_PHASE(5);
 }
 
-// Two kernels so that the common short classes (0, 1, narrow) are not register-allocated together with the long-window
-// classes (2, 3).  k_dp_band must stay within 208 VGPRs: k_replay and the other helper kernels of the calls in flight
-// (<= 96 VGPRs, no LDS) then fit next to two of its waves on a SIMD (216 + 216 + 96 > 512: 152 M reads/s instead of 216 M).
-// SET 0: classes 1, 0, then the narrow class;  SET 1: classes 3, 2.  Each wave pulls chunks from the set's queue until it is
-// empty (chunks of the most expensive class first).
+// Two kernels so that the common short classes (8 and 16 lanes per read) are not register-allocated together with the long-
+// window classes (32 and 64 lanes).  k_dp_band must stay within 208 VGPRs: k_replay and the other helper kernels of the
+// calls in flight (<= 96 VGPRs, no LDS) then fit next to two of its waves on a SIMD (216 + 216 + 96 > 512: 152 M reads/s
+// instead of 216 M).  SET 0: classes 1, 5, 0, 4;  SET 1: classes 3, 7, 2, 6.  Each wave pulls chunks from the set's queue until
+// it is empty (chunks of the most expensive class first).
 template <int SET>
 __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
-    constexpr int CA = SET ? 3 : 1, CB = SET ? 2 : 0, CC = SET ? -1 : kBandNarrowClass;
-    const int nA = min(a.counters[kCntClass0 + kBandClass0 + CA], a.list_stride);
-    const int nB = min(a.counters[kCntClass0 + kBandClass0 + CB], a.list_stride);
-    const int nC = CC >= 0 ? min(a.counters[kCntClass0 + kBandClass0 + (CC >= 0 ? CC : 0)], a.list_stride) : 0;
-    if (nA + nB + nC <= 0) return;
+    constexpr int C0 = SET ? 3 : 1, C1 = SET ? 7 : 5, C2 = SET ? 2 : 0, C3 = SET ? 6 : 4;
+    const int n0_ = min(a.counters[kCntClass0 + kBandClass0 + C0], a.list_stride);
+    const int n1_ = min(a.counters[kCntClass0 + kBandClass0 + C1], a.list_stride);
+    const int n2_ = min(a.counters[kCntClass0 + kBandClass0 + C2], a.list_stride);
+    const int n3_ = min(a.counters[kCntClass0 + kBandClass0 + C3], a.list_stride);
+    if (n0_ + n1_ + n2_ + n3_ <= 0) return;
     // the two row-word tables sit in front of the per-wave regions
     constexpr int kTblBytes = 2 * kBandTblBytes;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kTblBytes + 4 * kBandWaveLds + kLdsSlack];
@@ -525,27 +526,29 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
     }
     __syncthreads();
     uint8_t* const Lw = lds + kTblBytes + (threadIdx.x >> 6) * kBandWaveLds;
-    constexpr int GA = band_class_G(CA), GB = band_class_G(CB), GC = band_class_G(CC >= 0 ? CC : 0);
-    constexpr int perA = 64 / GA, perB = 64 / GB, perC = 64 / GC;   // reads per wave
-    const int chA = (nA + perA - 1) / perA, chB = (nB + perB - 1) / perB, chC = (nC + perC - 1) / perC;
+    constexpr int G01 = band_class_G(C0), G23 = band_class_G(C2);   // (C1 / C3: the same lane counts, 12 diagonals)
+    constexpr int per01 = 64 / G01, per23 = 64 / G23;   // reads per wave
+    const int ch0 = (n0_ + per01 - 1) / per01, ch1 = (n1_ + per01 - 1) / per01, ch2 = (n2_ + per23 - 1) / per23, ch3 = (n3_ + per23 - 1) / per23;
+    const int e0 = ch0, e1 = e0 + ch1, e2 = e1 + ch2, e3 = e2 + ch3;   // chunk index ranges of the four classes
     const int lane = threadIdx.x & 63;
     auto pop = [&]() {
         int c = 0;
         if (lane == 0) c = atomicAdd(&a.counters[kCntNextBand + SET], 1);
         return __builtin_amdgcn_readfirstlane(c);
     };
-    // record of this lane's item in chunk c (chunks of the wider class come first)
+    // record of this lane's item in chunk c (chunks of the wider classes come first)
     auto fetch = [&](int c, bool& act, int4& q0, int4& q1, int4& q2) -> int {
-        int cls = CA, it = 0, cnt = 0;
-        if (c < chA) { cls = CA; it = c * perA + lane / GA; cnt = nA; }
-        else if (c - chA < chB) { cls = CB; it = (c - chA) * perB + lane / GB; cnt = nB; }
-        else if (c - chA - chB < chC) { cls = CC; it = (c - chA - chB) * perC + lane / GC; cnt = nC; }
+        int cls = C0, it = 0, cnt = 0, G_ = G01;
+        if (c < e0) { cls = C0; it = c * per01 + lane / G01; cnt = n0_; }
+        else if (c < e1) { cls = C1; it = (c - e0) * per01 + lane / G01; cnt = n1_; }
+        else if (c < e2) { cls = C2; it = (c - e1) * per23 + lane / G23; cnt = n2_; G_ = G23; }
+        else if (c < e3) { cls = C3; it = (c - e2) * per23 + lane / G23; cnt = n3_; G_ = G23; }
         act = it < cnt;
         if (act) {
             const int4* rec = a.band_recs + ((size_t)cls * a.list_stride + it) * 3;
             q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
         }
-        return band_class_G(cls);   // lanes per item of that chunk
+        return G_;   // lanes per item of that chunk
     };
     // Touch the window bytes of an item one chunk early (one byte per 64-byte line, a line per lane of the group), so
     // that the staging loop of its chunk finds them in cache.  The loaded byte itself is never used.
@@ -561,7 +564,7 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
     bool act = false;
     int4 q0 = make_int4(0, 0, 0, 0), q1 = q0, q2 = q0;
     (void)fetch(c, act, q0, q1, q2);
-    while (c < chA + chB + chC) {
+    while (c < e3) {
         __builtin_amdgcn_wave_barrier();   // the wave enters every iteration whole (see k_realign_dp)
         // the next chunk is taken, its records are fetched and its window bytes touched while this one is being processed.
         // Of the records only what the touch needs stays in registers across the two passes (three values, not twelve: the
@@ -580,9 +583,10 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
             ndb_n = n0.z + n0.w + n1.x;
         };
         auto nextC = [&]() { sink = touch(act_n, so_n, ndb_n, g_n); };
-        if (c < chA) band_wave<CA>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
-        else if (CC < 0 || c < chA + chB) band_wave<CB>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
-        else band_wave<(CC >= 0 ? CC : CB)>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
+        if (c < e0) band_wave<C0>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
+        else if (c < e1) band_wave<C1>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
+        else if (c < e2) band_wave<C2>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
+        else band_wave<C3>(a, act, q0, q1, q2, Lw, s_enc, s_tbl, nextA, nextB, nextC);
         c = cn;
         (void)fetch(c, act, q0, q1, q2);
         // the touch load's destination register stays reserved until the load has certainly landed

@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     if (cells) {
         atomicAdd(&s_cells, cells);
         atomicAdd(band_list >= 0 ? &s_bytes_band : &s_bytes_exact, ndb + 16);
-        if (band_list >= kBandClass0 + 2 && band_list <= kBandClass0 + 3) atomicAdd(&s_bytes_wide, ndb + 16);   // k_dp_band_wide's classes
+        if (band_list >= 0 && band_class_wide_kernel(band_list - kBandClass0)) atomicAdd(&s_bytes_wide, ndb + 16);   // k_dp_band_wide's classes
         if (first_c == kLongClass) atomicAdd(&s_bytes_long, ndb + 16);
     }
     __syncthreads();

@@ -122,7 +122,7 @@ STRK_HD SearchResult search_replay(int32_t start, int32_t step, int32_t lsr, int
 // ---------------------------------------------------------------------------------------------
 struct BandGeo {
     int32_t ok;      // eligible for the band kernel
-    int32_t cls;     // band class 0..4 (band_class_G / band_class_D)
+    int32_t cls;     // band class 0..7 (band_class_G / band_class_D)
     int32_t G;
     int32_t wd;      // forward band width in diagonals = D * G (128, 256, 512, 1024; 96 for the narrow class)
     int32_t dlo;     // forward band: d in [dlo, dlo + wd)
@@ -133,26 +133,27 @@ struct BandGeo {
     int32_t ncol;    // number of such columns: (n - 1) * m + wd
 };
 
-// Band classes: 0..3 = 8 << c lanes per read x 16 diagonals per lane; 4 = the narrow class, 8 lanes x 12 diagonals, for
-// short motifs (the candidate sizes of a window of +-W span 2 W |motif| diagonals: motifs of up to 4 bases leave a band of
-// 96 as much slack as longer ones have in 128).
-// Per-class limits (what the class's LDS layout holds).  Classes 2 and 3 generate the forward row
-// symbols on the fly (left flank <= 255 rows from LDS, then the motif with a running phase).
-constexpr int kNumBandClasses = 5;
-constexpr int kBandNarrowClass = 4;
-STRK_HD constexpr int band_class_G(int c) { return c == kBandNarrowClass ? 8 : 8 << c; }
-STRK_HD constexpr int band_class_D(int c) { return c == kBandNarrowClass ? 12 : 16; }
+// Band classes: 0..3 = 8 << c lanes per read x 16 diagonals per lane (bands of 128, 256, 512, 1 024); 4..7 = the same lane
+// counts x 12 diagonals (96, 192, 384, 768).  The candidate sizes of a window of +-W span 2 W |motif| diagonals, so the band a
+// read needs follows its motif length: motifs of up to 4 bases leave a band of 96 as much slack as longer ones have in 128,
+// motifs of ~17 need 330 diagonals at W = 8 (BASELINE config 4's long motifs: 384 instead of 512).
+// Per-class limits (what the class's LDS layout holds: class c lives in the layout of class c & 3).  Lane counts of 32 and 64
+// generate the forward row symbols on the fly (left flank <= 255 rows from LDS, then the motif with a running phase).
+constexpr int kNumBandClasses = 8;
+STRK_HD constexpr int band_class_layout(int c) { return c & 3; }
+STRK_HD constexpr int band_class_G(int c) { return 8 << (c & 3); }
+STRK_HD constexpr int band_class_D(int c) { return c >= 4 ? 12 : 16; }
 STRK_HD constexpr int band_class_wd(int c) { return band_class_G(c) * band_class_D(c); }
-STRK_HD constexpr int band_class_layout(int c) { return c == kBandNarrowClass ? 0 : c; }   // the narrow class lives in class 0's LDS layout
-STRK_HD constexpr int band_max_db(int c) { return (c == 0 || c == kBandNarrowClass) ? 448 : (c == 1 ? 1024 : (c == 2 ? 4096 : 12288)); }
-STRK_HD constexpr int band_max_col(int c) { return (c == 0 || c == kBandNarrowClass) ? 320 : (c == 1 ? 512 : (c == 2 ? 1024 : 1536)); }
-STRK_HD constexpr bool band_class_fly(int c) { return c == 2 || c == 3; }
+STRK_HD constexpr int band_max_db(int c) { return (c & 3) == 0 ? 448 : ((c & 3) == 1 ? 1024 : ((c & 3) == 2 ? 4096 : 12288)); }
+STRK_HD constexpr int band_max_col(int c) { return (c & 3) == 0 ? 320 : ((c & 3) == 1 ? 512 : ((c & 3) == 2 ? 1024 : 1536)); }
+STRK_HD constexpr bool band_class_fly(int c) { return (c & 3) >= 2; }
 // classes that track the running maximum of the last column (alignments that end there above the fork row): all but the
 // narrowest ones, where the bound on those alignments never reaches a good read's score (motifs of up to ~9 bases)
-STRK_HD constexpr bool band_class_lmax(int c) { return c >= 1 && c <= 3; }
+STRK_HD constexpr bool band_class_lmax(int c) { return (c & 3) >= 1; }
+STRK_HD constexpr bool band_class_wide_kernel(int c) { return (c & 3) >= 2; }   // k_dp_band_wide's classes
 constexpr int kBandMaxFlank = 127;
 constexpr int kBandRowSlack = 96;    // prefix rows a band item may have beyond |db|
-constexpr int kBandNarrowSlack = 22; // diagonals the narrow class keeps free on each side of the candidates' span
+constexpr int kBandNarrowSlack = 22; // diagonals a 12-diagonal class keeps free on each side of the candidates' span, at least
 
 STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, int32_t lo, int32_t n) {
     BandGeo b = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -167,13 +168,13 @@ STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, 
     if (smin < 12) smin = 12;
     const int64_t rows = (int64_t)nfl + (int64_t)(lo + n - 1) * m;
     int32_t cls = -1;
-    for (int32_t k = 0; k < kNumBandClasses && cls < 0; ++k) {   // narrowest class that holds band and window
-        const int32_t c = k == 0 ? kBandNarrowClass : k - 1;
+    for (int32_t k = 0; k < kNumBandClasses && cls < 0; ++k) {   // narrowest class that holds band and window: 96, 128, 192, 256, ...
+        const int32_t c = (k >> 1) + ((k & 1) ? 0 : 4);
 #ifdef STRK_NO_NARROW
-        if (c == kBandNarrowClass) continue;
+        if (c >= 4) continue;
 #endif
         const int64_t w = band_class_wd(c);
-        const int64_t slack = (c == kBandNarrowClass && smin < kBandNarrowSlack) ? kBandNarrowSlack : smin;
+        const int64_t slack = (c >= 4 && smin < kBandNarrowSlack) ? kBandNarrowSlack : smin;
         if (span_hi - span_lo + 1 + 2 * slack > w) continue;
         if (ndb > band_max_db(c) || (int64_t)(n - 1) * m + w > band_max_col(c) || rows > band_max_db(c) + kBandRowSlack) continue;
         if (band_class_fly(c) && nfl > 255) continue;
@@ -183,7 +184,7 @@ STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, 
     const int32_t wd = band_class_wd(cls);
     // (a band wider than the window covers the whole matrix: such short windows cost no more here than in the exact
     // kernel and spare it a launch that only a handful of reads would use)
-    if (cls >= 1 && cls <= 3 && (int64_t)wd * 5 > (ndb + 1) * 4) return b;   // a wide band must drop at least a fifth of the columns
+    if ((cls & 3) >= 1 && (int64_t)wd * 5 > (ndb + 1) * 4) return b;   // a wide band must drop at least a fifth of the columns
     const int64_t extra = wd - (span_hi - span_lo + 1);
     b.ok = 1;
     b.cls = cls;

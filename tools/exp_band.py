@@ -17,16 +17,18 @@ from strkit_amd import _lib
 from strkit_amd.batch import batch_struct, make_params
 from strkit_amd.synth import make_config, LocusBatch
 cfg = int(sys.argv[1]); nb = int(sys.argv[2])
-b = LocusBatch.concat([make_config(cfg, seed_shift=k) for k in range(nb)])
+n_loci = {4: 21250, 5: 250}.get(cfg)
+b = LocusBatch.concat([make_config(cfg, n_loci=n_loci, seed_shift=k) for k in range(nb)])
 L = _lib.load(); ctx = _lib.default_context(0)
 s, keep = batch_struct(b); p = make_params(); st = _lib.StrkStats()
 outs = [np.zeros(b.n_reads, np.int32) for _ in range(4)]
 tb, td, tk = [], [], []
-for i in range(14):
+tw = []
+for i in range(16):
     L.strk_count_loci(ctx.handle, C.byref(s), C.byref(p), *[o.ctypes.data for o in outs], C.byref(st))
-    if i >= 10: tb.append(st.band_kernel_ms); td.append(st.dp_kernel_ms); tk.append(st.kernel_ms)
+    if i >= 12: tb.append(st.band_kernel_ms); td.append(st.dp_kernel_ms); tk.append(st.kernel_ms); tw.append(st.band_wide_kernel_ms)
 h = hashlib.sha1(b"".join(o.tobytes() for o in outs)).hexdigest()[:12]
-print("band %.4f ms  exact %.4f ms  all %.4f ms  (head %.3f wide %.3f long %.3f generic %.3f replay %.3f)  band_reads %d fb %d win %d  cells %.3g  sha %s" % (sum(tb)/len(tb), sum(td)/len(td), sum(tk)/len(tk), st.head_ms, st.band_wide_kernel_ms, st.long_kernel_ms, st.generic_kernel_ms, st.replay_ms, st.n_band_reads, st.n_band_fallback, st.window_used, st.dp_cells, h))
+print("band %.4f ms  exact %.4f ms  all %.4f ms  (head %.3f wide %.3f long %.3f generic %.3f replay %.3f)  band_reads %d fb %d win %d  cells %.3g  sha %s" % (sum(tb)/len(tb), sum(td)/len(td), sum(tk)/len(tk), st.head_ms, sum(tw)/len(tw), st.long_kernel_ms, st.generic_kernel_ms, st.replay_ms, st.n_band_reads, st.n_band_fallback, st.window_used, st.dp_cells, h))
 '''
 
 
@@ -46,7 +48,7 @@ def main():
         libs[os.path.basename(p)[:-3]] = p
     if args:
         libs = {k: v for k, v in libs.items() if k in args or k == "product"}
-    nb = {2: 10, 3: 10, 4: 10, 5: 1}.get(cfg, 10)
+    nb = {2: 10, 3: 1, 4: 1, 5: 1}.get(cfg, 10)
     runs = [(name, path, None) for name, path in libs.items()] + [(f"product dbg={d}", libs["product"], d) for d in dbgs]
     for name, path, dbg in runs:
         env = dict(os.environ, STRKIT_AMD_LIB=path, STRKIT_AMD_NO_PIPE="1")   # (one call = one launch of every kernel)
