@@ -466,7 +466,9 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
             const int per = 64 / band_class_G(k);
             wide_chunks += (c->h_counters[kCntClass0 + kBandClass0 + k] + per - 1) / per;
         }
-        c->hist_valid = true;
+        // (a call on band probation sent all but its first reads to the exact kernels: its queue lengths say nothing about the
+        // next call's — a one-block grid then crawled through 30 000 wide-band chunks in 46 ms, profiles/README.md round 3)
+        c->hist_valid = !(c->p_args.band_mode && c->p_args.band_limit != INT32_MAX);
         c->hist_band_mode = c->p_args.band_mode;
         c->hist_reads = std::max(1, b->n_reads);
         c->hist_exact_chunks = exact_chunks;

@@ -17,9 +17,13 @@ out = {}
 
 
 def full(v, frac=0.5):
-    """the full-size launches of a kernel: readings of at least `frac` of the largest one"""
-    top = max(v)
-    return [x for x in v if x >= frac * top] if top > 0 else list(v)
+    """the full-size launches of a kernel: readings within [frac, 1 / frac] of the median of the larger half of all readings
+    (the priming / parity-check calls of bench.py are smaller than a timed step; the first call after band probation runs some
+    kernels on a one-block grid and is an outlier the other way)"""
+    s = sorted(v, reverse=True)
+    h = s[:max(1, len(s) // 2)]
+    med = h[len(h) // 2]
+    return [x for x in v if frac * med <= x <= med / frac] if med > 0 else list(v)
 
 
 def short(name):
@@ -51,6 +55,9 @@ if len(sys.argv) > 3:
     for k, v in keep.items():
         if k in out.get("trace_p1", {}):
             v["unoverlapped_avg_us"] = out["trace_p1"][k]["avg_us"]
+            # effective clock of the launch: GRBM_GUI_ACTIVE sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+            if v.get("GRBM_GUI_ACTIVE") and v["unoverlapped_avg_us"] > 300:
+                v["clock_ghz"] = v["GRBM_GUI_ACTIVE"] / 8.0 / (v["unoverlapped_avg_us"] * 1e3)
     json.dump(keep, open(sys.argv[3], "w"), indent=1)
 json.dump(out, open(sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "summary.json"), "w"), indent=1)
 for trace in ("trace", "trace_p1"):
