@@ -268,7 +268,9 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
             def open_reader():
                 t_ = time.perf_counter()
                 try:
-                    whole = small or not has_index
+                    # under torch.distributed a file with an index is read in spans whatever its size: a rank's blocks are one
+                    # run of the catalog, so the spans it loads cover its share of the file only
+                    whole = (small and not (_distributed() and has_index)) or not has_index
                     try:
                         opened.append(DeviceBam(path, device=dev, span_bytes=None if whole else span_bytes))
                     except _lib.StrkError as e:
@@ -328,7 +330,10 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
 
     try:
         if _distributed():          # launched under torch.distributed (one rank per GPU): shard the blocks
-            results, n_depth, tm = call_blocks_sharded(blocks, run, ref, respect_ref)
+            # a reader that loads what its blocks need (spans of the file / blocks through the index) gets ONE run of
+            # consecutive blocks: every rank then reads and inflates its own byte range of the file, not the whole of it
+            ranged = (isinstance(bam, DeviceBam) and bam.streamed) or isinstance(bam, IndexedBam)
+            results, n_depth, tm = call_blocks_sharded(blocks, run, ref, respect_ref, contiguous=ranged)
         else:
             results, n_depth, tm = run(blocks)
     finally:
@@ -341,6 +346,9 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
     if own_reader and isinstance(bam, DeviceBam):
         tm["open_wait_s"] = t_wait              # what this thread still waited for the reader after catalog + reference side
     tm["front_end"] = "device" if isinstance(bam, DeviceBam) else "host"
+    if isinstance(bam, DeviceBam) and bam.streamed:      # this rank's own share of the file (compressed bytes read, uploaded, inflated)
+        tm["front_end_compressed_mb"] = bam.open_stage_s.get("compressed_mb", 0.0)
+        tm["front_end_spans"] = bam.open_stage_s.get("spans", 0)
     if fe_kernel_s is not None:
         tm["front_end_device_s"] = fe_kernel_s      # inflation + record scan + extraction kernels (HIP events)
         tm["open_stage_s"] = dict(getattr(bam, "open_stage_s", {}))
@@ -360,10 +368,24 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
             "runtime": time.perf_counter() - t0, "stage_times": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm.items()}}
 
 
-def deal_locus_blocks(blocks: list[list[Locus]], world: int) -> list[list[int]]:
-    """Deterministic longest-processing-time dealing of locus blocks to `world` ranks (indices into `blocks`),
-    balanced by an estimate of the DP work: sum over loci of (tract + flanks) squared."""
+def deal_locus_blocks(blocks: list[list[Locus]], world: int, contiguous: bool = False) -> list[list[int]]:
+    """Deterministic dealing of locus blocks to `world` ranks (indices into `blocks`), balanced by an estimate of the DP
+    work: sum over loci of (tract + flanks) squared.  contiguous = False: longest-processing-time scatter (the best balance; the
+    counting path, where a rank holds every read anyway).  contiguous = True: every rank gets ONE run of consecutive blocks
+    whose cost is as close to an equal share as a prefix split allows — the file path: a rank then reads, uploads and inflates
+    only the byte range of the alignment file its own blocks lie in (the reference's workers take consecutive blocks of a
+    contig off one queue, call_sample.py:103-138,414-420)."""
     cost = [sum((l.right_coord - l.left_coord + 2 * l.flank_size) ** 2 for l in blk) for blk in blocks]
+    if contiguous:
+        total = float(sum(cost)) or 1.0
+        owner_c: list[list[int]] = [[] for _ in range(world)]
+        acc = 0.0
+        for k, c in enumerate(cost):
+            # the rank whose share the block's midpoint falls into
+            r = min(world - 1, int((acc + c / 2.0) / total * world))
+            owner_c[r].append(k)
+            acc += c
+        return owner_c
     load = [0] * world
     owner: list[list[int]] = [[] for _ in range(world)]
     for k in sorted(range(len(blocks)), key=lambda i: (-cost[i], i)):
@@ -452,7 +474,8 @@ def _gather_padded(t, dist, device):
     return [out[w, :int(ns[w, 0])] for w in range(world)]
 
 
-def call_blocks_sharded(blocks, call_fn, ref: Fasta | None = None, respect_ref: bool = False) -> tuple[list[dict], int, dict]:
+def call_blocks_sharded(blocks, call_fn, ref: Fasta | None = None, respect_ref: bool = False,
+                        contiguous: bool = False) -> tuple[list[dict], int, dict]:
     """One process per GPU (`--processes N` of the reference <-> N ranks of a torch.distributed job): every rank calls
     its share of the locus blocks with `call_fn(blocks) -> (results, reads kept, stage times)` and all ranks get the
     merged results ordered by locus index, as the reference's ordered merge does (call_sample.py:195-197,420).
@@ -463,7 +486,7 @@ def call_blocks_sharded(blocks, call_fn, ref: Fasta | None = None, respect_ref: 
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    mine = [blocks[k] for k in deal_locus_blocks(blocks, world)[rank]]
+    mine = [blocks[k] for k in deal_locus_blocks(blocks, world, contiguous)[rank]]
     results, _n_depth, tm = call_fn(mine) if mine else ([], 0, {})
     loci_t, reads_t, names_t = _encode_rows(results, tm.get("errors", []))
     g_loci = _gather_padded(torch.from_numpy(loci_t), dist, device)

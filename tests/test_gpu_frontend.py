@@ -415,15 +415,15 @@ def _two_rank_call_worker(rank, world, port, paths, q):
     from strkit_amd.frontend import call_sample
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     rep = call_sample(paths["bam"], paths["ref"], paths["loci"])
-    q.put((rank, rep["results"], rep["stage_times"].get("front_end"), rep["catalog"]))
+    q.put((rank, rep["results"], rep["stage_times"].get("front_end"), rep["catalog"], rep["stage_times"].get("front_end_compressed_mb")))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_ranks_from_files_give_the_single_process_report(gpu_ctx, tmp_path):
     """`call_sample` under torch.distributed (world size 2, gloo, both ranks on this box's GPU): every rank opens the file with
-    the device front end, calls its share of the locus blocks, and all ranks end with the report of a single process — the
-    fixed-size record gather of call_blocks_sharded on real rows."""
+    the device front end in spans, calls its own run of consecutive locus blocks — loading less than 60 % of the file for it —
+    and all ranks end with the report of a single process: the fixed-size record gather of call_blocks_sharded on real rows."""
     import socket
 
     import torch.multiprocessing as mp
@@ -443,6 +443,9 @@ def test_two_ranks_from_files_give_the_single_process_report(gpu_ctx, tmp_path):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, rows, fe, cat in got:
+    file_mb = os.path.getsize(t["paths"]["bam"]) / 1e6
+    for rank, rows, fe, cat, comp_mb in got:
         assert fe == "device" and cat == want["catalog"]
         assert rows == want["results"], rank
+        # one run of consecutive catalog blocks per rank: a rank reads, uploads and inflates its own byte range of the file only
+        assert comp_mb is not None and 0 < comp_mb < 0.6 * file_mb, (rank, comp_mb, file_mb)

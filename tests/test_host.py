@@ -330,3 +330,31 @@ def test_realign_i16_saturation_flags():
     assert out.tolist() == [0, _lib.STRK_I16_CELL_MAY_SATURATE,
                             _lib.STRK_I16_CELL_MAY_SATURATE | _lib.STRK_I16_SCORE_SATURATES, 0]
     assert lib.strk_realign_i16_flags(1, None, s2.ctypes.data, score.ctypes.data, out.ctypes.data) == -22
+
+
+def test_contiguous_block_dealing_gives_every_rank_one_balanced_run():
+    """The file path deals ONE run of consecutive catalog blocks to every rank (a rank then loads only its own byte range of the
+    alignment file), balanced by the same cost estimate as the scatter of the counting path."""
+    from strkit_amd.frontend.call import deal_locus_blocks
+    from strkit_amd.frontend.loci import Locus
+    rng = np.random.default_rng(9)
+    blocks = []
+    pos = 1000
+    for b in range(57):
+        blk = []
+        for _ in range(int(rng.integers(1, 200))):
+            n = int(rng.integers(6, 400))
+            blk.append(Locus(len(blk), f"l{b}_{len(blk)}", "chr1", pos, pos + n, "CAG", 70))
+            pos += n + 500
+        blocks.append(blk)
+    cost = [sum((l.right_coord - l.left_coord + 140) ** 2 for l in blk) for blk in blocks]
+    for world in (1, 2, 3, 8):
+        runs = deal_locus_blocks(blocks, world, contiguous=True)
+        assert sorted(k for r in runs for k in r) == list(range(len(blocks)))
+        for r in runs:
+            assert r == list(range(r[0], r[-1] + 1)) if r else True          # one run of consecutive blocks
+        assert [r[0] for r in runs if r] == sorted(r[0] for r in runs if r)  # in catalog order over the ranks
+        share = sum(cost) / world
+        assert max(sum(cost[k] for k in r) for r in runs) < share + max(cost), world
+    # the scatter (counting path) stays what it was: every block exactly once
+    assert sorted(k for r in deal_locus_blocks(blocks, 3) for k in r) == list(range(len(blocks)))
