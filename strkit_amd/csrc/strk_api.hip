@@ -724,6 +724,13 @@ int strk_count_loci_dseqs(strk_ctx* ctx, const strk_batch* batch, const void* d_
     if (stats) memset(stats, 0, sizeof *stats);
     strk_batch d;
     int rc;
+    if (d_seqs) {   // bases that are on the device already must be on THIS context's device (no peer access is set up)
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, d_seqs) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != ctx->device) {
+            (void)hipGetLastError();
+            return fail(STRK_E_INVALID, "d_seqs is not device memory of device %d (the context's)", ctx->device);
+        }
+    }
     if (!d_seqs) {   // host bases: large batches go through the pinned three-slot pipeline (strk_host_pipe.inc)
         bool taken = false;
         rc = count_loci_pipelined(ctx, batch, params, out_cn, out_score, out_n_iters, out_start, stats, &taken);

@@ -9,7 +9,10 @@ namespace strk {
 // ---------------------------------------------------------------------------------------------
 constexpr int kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;  // gfx9 DPP controls, present on gfx950
 constexpr int kCLMax = 40;   // columns per lane of the largest class
-constexpr int kStairMinG = 32;   // classes with at least this many lanes per read fold fork rows along a staircase (bwd_pass)
+#ifndef STRK_STAIR_MIN_G
+#define STRK_STAIR_MIN_G 16   // (config 3 on one MI355X: 7.97 ms per 200 000 reads at 32, 7.68 at 16, 7.76 at 8)
+#endif
+constexpr int kStairMinG = STRK_STAIR_MIN_G;   // classes with at least this many lanes per read fold fork rows along a staircase (bwd_pass)
 constexpr int kNQMax = kCLMax / 4;
 
 constexpr int kDppRowShr1 = 0x111, kDppRowShl1 = 0x101;

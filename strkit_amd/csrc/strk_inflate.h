@@ -100,7 +100,7 @@ STRK_INF_HD bool build(const uint8_t* lens, int n, uint8_t* sym, Code* c) {
     for_each_length([&](auto lc) {
         constexpr int l = decltype(lc)::value + 1;
         const int cnt = count[l] & 0xffff, lits = count[l] >> 16;
-        left <<= 1;
+        left *= 2;                                       // (may be negative once over-subscribed: not a shift)
         left -= cnt;
         over |= left < 0;                                // over-subscribed
         code <<= 1;                                      // first code of length l
@@ -142,7 +142,12 @@ struct Stream {
     int cnt;              // valid bits in buf
 };
 
-STRK_INF_HD void load_ahead(Stream& s) { memcpy(&s.ahead, s.p, 8); }
+// (never further than the padding: a stream that has run past its payload keeps re-loading the last padded bytes until the
+// overrun check behind the refill reports it — a truncated or crafted block cannot make the decoder read elsewhere)
+STRK_INF_HD void load_ahead(Stream& s) {
+    const uint8_t* q = s.p <= s.end + 8 ? s.p : s.end + 8;
+    memcpy(&s.ahead, q, 8);
+}
 STRK_INF_HD void refill(Stream& s) {
     s.buf |= s.ahead << s.cnt;
     s.p += (63 - s.cnt) >> 3;
@@ -158,7 +163,10 @@ STRK_INF_HD uint32_t take(Stream& s, int n) {   // n <= 32 bits, LSB first
 
 // Reads a dynamic block header (HLIT, HDIST, HCLEN, the code-length code, the two sets of lengths) and builds the tables.
 STRK_INF_HD int read_dynamic(Stream& s, Tables* t, uint8_t* lens, Code* ll, Code* dl) {
+    // (every refill of the header is followed by the check the literal loop has: a truncated or crafted header must not walk
+    // the stream further than the 16 bytes of padding the caller promises behind the payload)
     refill(s);
+    if (s.p - 8 > s.end) return kErrOverrun;
     const int nlen = (int)take(s, 5) + 257, ndist = (int)take(s, 5) + 1, ncode = (int)take(s, 4) + 4;
     if (nlen > 286 || ndist > 30) return kErrBadLengths;
     // the order of the code-length code's lengths: 16 17 18 0 8 7 9 6 10 5 11 4 | 12 3 13 2 14 1 15, five bits each
@@ -169,7 +177,10 @@ STRK_INF_HD int read_dynamic(Stream& s, Tables* t, uint8_t* lens, Code* ll, Code
     for (int i = 0; i < 19; ++i) lens[i] = 0;
     STRK_INF_LOOP
     for (int i = 0; i < ncode; ++i) {
-        if (s.cnt < 3) refill(s);
+        if (s.cnt < 3) {
+            refill(s);
+            if (s.p - 8 > s.end) return kErrOverrun;
+        }
         const int at = (int)((i < 12 ? order_lo >> (5 * i) : order_hi >> (5 * (i - 12))) & 31);
         lens[at] = (uint8_t)take(s, 3);
     }
@@ -181,6 +192,7 @@ STRK_INF_HD int read_dynamic(Stream& s, Tables* t, uint8_t* lens, Code* ll, Code
     STRK_INF_LOOP
     while (i < nlen + ndist) {
         refill(s);
+        if (s.p - 8 > s.end) return kErrOverrun;
         const uint32_t v = bitrev15((uint32_t)s.buf);
         const uint32_t w = code_word(v, cl);
         const int len = (int)(w >> 28);
@@ -313,7 +325,10 @@ STRK_INF_HD int inflate_block(const uint8_t* in, int in_len, uint8_t* out, int o
         if (!in_block) {
             flush();
             if (last) break;
-            if (s.cnt < 48) refill(s);
+            if (s.cnt < 48) {
+                refill(s);
+                if (s.p - 8 > s.end) return kErrOverrun;
+            }
             last = take(s, 1) != 0;
             const int type = (int)take(s, 2);
             if (type == 0) {

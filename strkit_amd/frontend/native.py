@@ -240,10 +240,13 @@ class IndexedBam:
         self.comp = np.memmap(path, np.uint8, "r")
         self.header_text, self.contigs, self._first = host_header(path, self.comp)
         index = index or (path + ".bai" if os.path.exists(path + ".bai") else os.path.splitext(path)[0] + ".bai")
-        self._lin = self._read_bai(index, len(self.contigs))
+        self._lin = self._read_bai(index, len(self.contigs), path)
 
     @staticmethod
-    def _read_bai(path: str, n_contigs: int) -> list[np.ndarray]:
+    def _read_bai(path: str, n_contigs: int, bam_path: str | None = None) -> list[np.ndarray]:
+        # an index older than its alignment file describes another file's record chain (as for the .fai, fasta.py)
+        if bam_path is not None and os.path.getmtime(path) + 1.0 < os.path.getmtime(bam_path):
+            raise ValueError(f"{path} is older than {bam_path}: re-index the alignment file")
         raw = np.fromfile(path, np.uint8)
         if raw[:4].tobytes() != b"BAI\x01":
             raise ValueError(f"{path}: not a BAI index")
@@ -397,7 +400,7 @@ class DeviceBam(_Records):
         index = index or (path + ".bai" if os.path.exists(path + ".bai") else os.path.splitext(path)[0] + ".bai")
         starts = [np.array([first], np.int64)]
         if os.path.exists(index):
-            lin = IndexedBam._read_bai(index, len(self.contigs))
+            lin = IndexedBam._read_bai(index, len(self.contigs), path)
             voff = np.unique(np.concatenate([x[x != 0] for x in lin] or [np.zeros(0, np.uint64)]).astype(np.uint64))
             if voff.size:
                 off = np.empty(voff.size, np.int64)

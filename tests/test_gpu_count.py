@@ -234,7 +234,7 @@ def test_narrow_band_class_takes_short_motifs(gpu_ctx):
 
 
 def test_staircase_fork_rows_in_the_wide_exact_classes(gpu_ctx):
-    """Windows of 449 bases and more run with 32 / 64 lanes per read and fold their fork rows along a staircase
+    """Windows of 321 bases and more run with 16 / 32 / 64 lanes per read and fold their fork rows along a staircase
     (strk_dp_exact.h); items whose smallest candidate has fewer motif rows than lanes take the per-lane fold, alone or in
     one chunk with others.  Noisy reads, long and short motifs, every end-flag family that the fold touches."""
     rng = np.random.default_rng(78)
@@ -244,6 +244,9 @@ def test_staircase_fork_rows_in_the_wide_exact_classes(gpu_ctx):
         hi = 1500 // mlen[1]
         loci.append(random_locus(rng, 4, motif_len=mlen, cn=(320 // mlen[0], max(330 // mlen[0], hi)), flank=(30, 70), edits=(0, 40), alpha=ALPHA_WC))
     loci.append(random_locus(rng, 4, motif_len=(19, 20), cn=(16, 18), flank=(70, 70), edits=(0, 6)))   # window reaches candidate 1
+    for k in range(12):                                                                                  # 16 lanes per read: windows of 321-448
+        mlen = (2, 5) if k % 2 else (8, 16)
+        loci.append(random_locus(rng, 4, motif_len=mlen, cn=(200 // mlen[1], 290 // mlen[1]), flank=(60, 70), edits=(0, 25), alpha=ALPHA_WC))
     b = LocusBatch.from_reads(loci)
     for flags, fb in ((15, True), (0, False), (5, True), (10, True)):
         got, st = _run(b, gpu_ctx, band=False, end_flags=flags, feedback=fb, window=15)

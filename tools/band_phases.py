@@ -25,6 +25,6 @@ print("%.4f %d %d" % (sum(t) / len(t), st.n_band_reads, st.n_band_fallback))
 names = {0: "all", 4: "no in-kernel search", 5: "no search, no forward pass", 6: "no search, no backward pass",
          12: "no search, no fork rows", 15: "nothing but staging", 16: "all, items in arrival order", 20: "no search, arrival order"}
 for dbg, name in names.items():
-    env = dict(os.environ, STRKIT_AMD_DBG=str(dbg))
+    env = dict(os.environ, STRKIT_AMD_DBG=str(dbg), STRKIT_AMD_NO_PIPE="1")
     out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
     print(f"dbg={dbg:2d} {name:28s} k_dp_band ms, band reads, fallbacks: {out.stdout.strip()} {out.stderr.strip()[-200:] if out.returncode else ''}", flush=True)
