@@ -485,7 +485,7 @@ def main() -> None:
                                "device_ms": iso["device_ms"],
                                "note": "one call at a time: kernel durations are un-overlapped"}
         # (b) the host-buffer entry point strk_count_loci: the batch starts in pageable host memory and the results end
-        # there, every step (sub-batches through three pinned slots: staging copy, H2D, kernels, D2H overlap)
+        # there, every step (sub-batches through four pinned slots and two compute contexts: staging copy, H2D, kernels, D2H overlap)
         nh = max(3, min(a.steps, 8))
         hb = [batch_struct(b) for b in batches[:min(NB, 3)]]
         outs = [np.zeros(n_reads_max, np.int32) for _ in range(4)]
@@ -503,7 +503,7 @@ def main() -> None:
                                    "sub_batches_per_step": int(st.n_dp_launches),
                                    "bytes_h2d_per_step": int(bl_h.seqs.nbytes + bl_h.n_reads * 24),
                                    "note": "strk_count_loci with pageable host buffers in and out, one call at a time; inside a call "
-                                           "sub-batches of whole loci travel through three pinned slots (strk_host_pipe.inc); never "
+                                           "sub-batches of whole loci travel through four pinned slots and two compute contexts (strk_host_pipe.inc); never "
                                            "the headline value"}
     if e2e_data is not None:
         progress("extras: end to end from files")

@@ -262,8 +262,9 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     static const int tune = getenv("STRKIT_AMD_DP_BLOCKS") ? atoi(getenv("STRKIT_AMD_DP_BLOCKS")) : 0;   // tuning aid
     // a call that shares the device with other calls in flight takes seven eighths of the CU slots per kernel, so
     // that the tail of one call and the head of the next co-run (this call is counted already).  tools/grid_sweep.sh on the
-    // bench workload, three calls in flight: 3/4 -> 199 M reads/s, 7/8 -> 206 M, all -> 165 M (the small kernels of the
-    // other calls fit next to resident band blocks: 2 x 208 of a SIMD's 512 VGPRs, no LDS of their own)
+    // bench workload, round 2, three calls in flight: 3/4 -> 199 M reads/s, 7/8 -> 206 M, all -> 165 M.  The free eighth is
+    // what lets the LDS-holding tail kernels of one call (k_dp_band_wide, k_dp_all, k_dp_long) start while another call's
+    // band pass is resident; k_hash / k_plan also fit NEXT to two band waves per SIMD (2 x 224 of 512 VGPRs, no LDS)
     const int eighths = g_calls_in_flight.load(std::memory_order_relaxed) > 1 ? 7 : 8;
     // expected chunks of the sparsely used kernels, from the previous call of this context (same band mode), scaled
     // to this batch with 50 % head-room; without history every grid is the full resident one.  A grid that turns

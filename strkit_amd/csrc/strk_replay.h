@@ -38,7 +38,10 @@ constexpr int kStopNone = 0, kStopRescore = 1, kStopMiss = 2;
 // in-order chain over the reads is wave-uniform ALU work on values fetched with v_readlane.
 // (at most 96 VGPRs: a wave of this kernel then fits next to the two resident waves of a band kernel on a SIMD, so that the
 // replay of one call runs inside the band pass of the next one instead of waiting for a free CU slot)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) k_replay(KArgs a, ReplayArgs p) {
+#ifndef STRK_REPLAY_WAVES
+#define STRK_REPLAY_WAVES 5   // waves per SIMD the register allocator aims at (tools/exp_build.sh variants)
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRK_REPLAY_WAVES, 8))) k_replay(KArgs a, ReplayArgs p) {
     const int l = blockIdx.x;
     const int lane = threadIdx.x;
     const int r_end = a.read_off[l + 1];

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic (GPU box): the bench loop (three calls in flight, eight rotating batches of the config-2 workload) with per-call
+"""Diagnostic (GPU box): the bench loop (several calls in flight, eight rotating batches of the config-2 workload) with per-call
 miss statistics and the host time spent inside strk_finish.  usage: STRKIT_AMD_LIB=... python tools/miss_probe.py [window]"""
 import ctypes as C
 import os
