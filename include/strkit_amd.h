@@ -146,6 +146,15 @@ const char* strk_version(void);
 /* free / total memory of a device in bytes (hipMemGetInfo): how the file front end decides whether an alignment file's
  * decompressed form stays resident or is streamed in spans. */
 int strk_device_mem(int device, int64_t* free_bytes, int64_t* total_bytes);
+/* Page-locks (hipHostRegister) / releases a host buffer the caller owns.  strk_count_loci copies the bases (batch.seqs) of a
+ * batch to the device by DMA straight from the caller's array when that lies in registered (or hipHostMalloc'ed) memory — no
+ * staging copy through the library's own pinned blocks, which is what bounds the pageable path (the reference's worker would
+ * register the per-block array it reuses, call_sample.py:103-138).  Registering costs a few milliseconds per 100 MB: worth
+ * it for buffers that are reused. */
+int strk_host_register(void* ptr, int64_t bytes);
+int strk_host_unregister(void* ptr);
+/* 1 if [ptr, ptr + bytes) is page-locked host memory the library would read in place, 0 if not. */
+int strk_host_is_pinned(const void* ptr, int64_t bytes);
 
 /* Scalar drop-in for strkit_rust_ext.get_repeat_count (repeats.py:58-68).  Return contract
  * (repeats.py:55-56): ((out_cn, out_score), out_n_explored, out_cn - start_count). */

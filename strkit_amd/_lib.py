@@ -48,7 +48,8 @@ class StrkStats(C.Structure):
 
 
 # Every symbol include/strkit_amd.h declares (tests check the .so exports exactly these).
-EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_device_mem", "strk_repeat_count", "strk_count_loci",
+EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_device_mem", "strk_host_register", "strk_host_unregister",
+           "strk_host_is_pinned", "strk_repeat_count", "strk_count_loci",
            "strk_count_loci_device", "strk_submit_loci_device", "strk_finish", "strk_score_table",
            "strk_score_ref_table", "strk_ref_repeat_count", "strk_ref_repeat_count_batch", "strk_realign", "strk_realign_i16_flags", "strk_bam_scan",
            "strk_extract_reads", "strk_bgzf_inflate", "strk_bgzf_inflate_range", "strk_bam_names", "strk_bam_scan_piece",
@@ -178,6 +179,12 @@ def load(build: bool = True):
         L.strk_device_mem.argtypes = [C.c_int, _i64p, _i64p]
         L.strk_realign_i16_flags.restype = C.c_int
         L.strk_realign_i16_flags.argtypes = [C.c_int32] + [C.c_void_p] * 4
+        L.strk_host_register.restype = C.c_int
+        L.strk_host_register.argtypes = [C.c_void_p, C.c_int64]
+        L.strk_host_unregister.restype = C.c_int
+        L.strk_host_unregister.argtypes = [C.c_void_p]
+        L.strk_host_is_pinned.restype = C.c_int
+        L.strk_host_is_pinned.argtypes = [C.c_void_p, C.c_int64]
         _lib = L
         return L
 
@@ -187,6 +194,22 @@ def device_mem(device: int = 0) -> tuple[int, int]:
     f, t = C.c_int64(), C.c_int64()
     check(load().strk_device_mem(int(device), C.byref(f), C.byref(t)))
     return f.value, t.value
+
+
+def host_register(arr) -> None:
+    """Page-locks a C-contiguous numpy array in place (strk_host_register): strk_count_loci then reads it by DMA where it
+    lies.  The array must stay alive, and must not be resized, until host_unregister."""
+    if arr.nbytes:
+        check(load().strk_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+
+def host_unregister(arr) -> None:
+    if arr.nbytes:
+        check(load().strk_host_unregister(C.c_void_p(arr.ctypes.data)))
+
+
+def host_is_pinned(arr) -> bool:
+    return bool(arr.nbytes) and bool(load().strk_host_is_pinned(C.c_void_p(arr.ctypes.data), arr.nbytes))
 
 
 def check(rc: int) -> None:

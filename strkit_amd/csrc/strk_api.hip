@@ -638,6 +638,23 @@ extern "C" {
 const char* strk_last_error(void) { return g_err.c_str(); }
 const char* strk_version(void) { return "strkit_amd 0.1.0 (gfx950)"; }
 
+int strk_host_register(void* ptr, int64_t bytes) {
+    if (!ptr || bytes <= 0) return fail(STRK_E_INVALID, "strk_host_register: null pointer or no bytes");
+    const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return 0; }
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(STRK_E_DEVICE, "hipHostRegister(%lld bytes): %s", (long long)bytes, hipGetErrorString(e)); }
+    return 0;
+}
+
+int strk_host_is_pinned(const void* ptr, int64_t bytes) { return bytes > 0 && host_range_pinned(ptr, (size_t)bytes) ? 1 : 0; }
+
+int strk_host_unregister(void* ptr) {
+    if (!ptr) return fail(STRK_E_INVALID, "strk_host_unregister: null pointer");
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(STRK_E_DEVICE, "hipHostUnregister: %s", hipGetErrorString(e)); }
+    return 0;
+}
+
 int strk_device_mem(int device, int64_t* free_bytes, int64_t* total_bytes) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(STRK_E_NODEV, "no HIP device visible");

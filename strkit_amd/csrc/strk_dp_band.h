@@ -484,9 +484,9 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
 }
 
 // Two kernels so that the common short classes (8 and 16 lanes per read) are not register-allocated together with the long-
-// window classes (32 and 64 lanes).  k_dp_band must stay within 208 VGPRs: k_replay and the other helper kernels of the
-// calls in flight (<= 96 VGPRs, no LDS) then fit next to two of its waves on a SIMD (216 + 216 + 96 > 512: 152 M reads/s
-// instead of 216 M).  SET 0: classes 1, 5, 0, 4;  SET 1: classes 3, 7, 2, 6.  Each wave pulls chunks from the set's queue until
+// window classes (32 and 64 lanes).  (Round 2 held k_dp_band to 208 VGPRs so that k_replay ran beside two of its waves per
+// SIMD with three calls in flight; with two calls in flight and the free eighth of the CU slots that no longer matters:
+// tools/grid_sweep2.sh, a k_replay of 64 VGPRs gains 1 %.)  SET 0: classes 1, 5, 0, 4;  SET 1: classes 3, 7, 2, 6.  Each wave pulls chunks from the set's queue until
 // it is empty (chunks of the most expensive class first).
 template <int SET>
 __device__ __forceinline__ void band_kernel_body(const KArgs& a) {

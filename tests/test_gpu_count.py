@@ -264,3 +264,40 @@ def test_unknown_narrowing_schedule_is_rejected(gpu_ctx):
     outs = [np.zeros(b.n_reads, np.int32) for _ in range(4)]
     rc = _lib.load().strk_count_loci(gpu_ctx.handle, C.byref(s), C.byref(p), *[o.ctypes.data for o in outs], None)
     assert rc == -22 and b"narrowing" in _lib.load().strk_last_error()
+
+
+@pytest.mark.gpu
+def test_host_entry_point_reads_page_locked_arrays_in_place(gpu_ctx):
+    """strk_host_register: the bases of a batch that are page-locked are uploaded by DMA from where they lie (no staging copy);
+    the results are those of the pageable path, and unregistering gives the pageable path back."""
+    import ctypes as C
+    from strkit_amd import _lib
+    from strkit_amd.batch import batch_struct, make_params, pin_batch, unpin_batch
+    from strkit_amd.synth import LocusBatch, make_config
+    b = LocusBatch.concat([make_config(2, n_loci=1000, seed_shift=70 + k) for k in range(3)])   # ~30 MB: several sub-batches
+    L = _lib.load()
+    p = make_params()
+
+    def run():
+        s, keep = batch_struct(b)
+        outs = [np.zeros(b.n_reads, np.int32) for _ in range(4)]
+        st = _lib.StrkStats()
+        _lib.check(L.strk_count_loci(gpu_ctx.handle, C.byref(s), C.byref(p), *[o.ctypes.data for o in outs], C.byref(st)))
+        return outs, int(st.n_dp_launches), keep
+
+    plain, n_sub, _ = run()
+    assert n_sub > 1
+    assert not _lib.host_is_pinned(b.seqs)
+    pin_batch(b)
+    try:
+        assert _lib.host_is_pinned(b.seqs)
+        locked, n_sub2, keep = run()
+        assert keep["seqs"].ctypes.data == b.seqs.ctypes.data   # batch_struct hands the registered arrays on, not copies
+        for x, y in zip(plain, locked):
+            assert np.array_equal(x, y)
+    finally:
+        unpin_batch(b)
+    assert not _lib.host_is_pinned(b.seqs)
+    again, _, _ = run()
+    for x, y in zip(plain, again):
+        assert np.array_equal(x, y)
