@@ -522,8 +522,43 @@ def main() -> None:
             if w >= 2:
                 r3 += batches[w % len(hb)].n_reads
         e3 = time.perf_counter() - t3
+        # (d) two callers at once, a context each (the reference runs N worker processes, call_sample.py:414): the tail of one
+        # caller's batch overlaps the head of the other's, PCIe is shared
+        import threading
+
+        def two_callers(n_calls):
+            outs2 = [[np.zeros(n_reads_max, np.int32) for _ in range(4)] for _ in range(2)]
+            stats2 = [_lib.StrkStats(), _lib.StrkStats()]
+            errs = []
+
+            def work(t, n):
+                try:
+                    for w in range(n):
+                        s_, _k = hb[(w + t) % len(hb)]
+                        _lib.check(L.strk_count_loci(ctxs[t].handle, C.byref(s_), C.byref(p), *[o.ctypes.data for o in outs2[t]], C.byref(stats2[t])))
+                except Exception as e:  # noqa: BLE001
+                    errs.append(e)
+            for n in (2, n_calls):     # (first round: the second context's pipeline is created)
+                th = [threading.Thread(target=work, args=(t, n)) for t in range(2)]
+                t0 = time.perf_counter()
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                el = time.perf_counter() - t0
+            if errs:
+                raise errs[0]
+            reads = sum(batches[(w + t) % len(hb)].n_reads for t in range(2) for w in range(n_calls))
+            return {"value": reads / el, "unit": "reads/s", "ms_per_call": el / n_calls * 1e3 / 2, "calls": 2 * n_calls}
+        if len(ctxs) >= 2:
+            progress("extras: host-buffer entry point, two callers")
+            extras["h2d_inclusive"]["two_callers_page_locked"] = two_callers(nh)
         for arr in pinned:
             _lib.host_unregister(arr)
+        if len(ctxs) >= 2:
+            extras["h2d_inclusive"]["two_callers"] = two_callers(nh)
+            extras["h2d_inclusive"]["two_callers"]["note"] = ("two threads, a context each, calling strk_count_loci at the same time (pageable "
+                                                             "buffers; two_callers_page_locked: registered bases)")
         extras["h2d_inclusive"]["page_locked"] = {
             "value": r3 / e3, "unit": "reads/s", "ms_per_step": e3 / nh * 1e3, "steps": nh,
             "register_ms_per_batch": pin_ms / len(hb),
