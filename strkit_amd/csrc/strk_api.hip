@@ -260,12 +260,12 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
                      hipStream_t st, bool time_dp, const ReplayArgs* pre_replay = nullptr) {
     hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, a, mode, d_items, n_items, force_generic);
     static const int tune = getenv("STRKIT_AMD_DP_BLOCKS") ? atoi(getenv("STRKIT_AMD_DP_BLOCKS")) : 0;   // tuning aid
-    // a call that shares the device with other calls in flight takes seven eighths of the CU slots per kernel, so
-    // that the tail of one call and the head of the next co-run (this call is counted already).  tools/grid_sweep.sh on the
-    // bench workload, round 2, three calls in flight: 3/4 -> 199 M reads/s, 7/8 -> 206 M, all -> 165 M.  The free eighth is
-    // what lets the LDS-holding tail kernels of one call (k_dp_band_wide, k_dp_all, k_dp_long) start while another call's
-    // band pass is resident; k_hash / k_plan also fit NEXT to two band waves per SIMD (2 x 224 of 512 VGPRs, no LDS)
-    const int eighths = g_calls_in_flight.load(std::memory_order_relaxed) > 1 ? 7 : 8;
+    // A call that shares the device with other calls in flight takes fifteen sixteenths of the CU slots per kernel: the free
+    // slots are what lets the LDS-holding tail kernels of one call (k_dp_band_wide, k_dp_all, k_dp_long) start while another
+    // call's band pass is resident; k_hash / k_plan / k_replay need no LDS and fit NEXT to two band waves per SIMD (2 x 184 of
+    // 512 VGPRs).  tools/grid_sweep2.sh, two calls in flight: 448 blocks 239 M reads/s, 480 -> 246 M, 496 -> 240 M, 512 -> 186 M
+    // (round 2, three calls in flight and 219 VGPRs: 7/8 was the best).
+    const int sixteenths = g_calls_in_flight.load(std::memory_order_relaxed) > 1 ? 15 : 16;
     // expected chunks of the sparsely used kernels, from the previous call of this context (same band mode), scaled
     // to this batch with 50 % head-room; without history every grid is the full resident one.  A grid that turns
     // out too small only makes that kernel slower: every wave pulls chunks until the queue is empty.
@@ -281,7 +281,7 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     int band_blocks = 1;
     if (band) {
         // banded first pass: certified reads are done, the others are appended to the exact lists below
-        band_blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * eighths / 8, (a.list_stride + 3) / 4));
+        band_blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * sixteenths / 16, (a.list_stride + 3) / 4));
         hipLaunchKernelGGL(k_dp_band, dim3(band_blocks), dim3(256), 0, st, a);
     }
     if (time_dp) (void)hipEventRecord(c->ev[kEvBand], st);
@@ -293,7 +293,7 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     if (!force_generic) {
         // persistent-style grid: every wave pulls chunks from the device-side queue until it is empty
         constexpr int kBlocksPerCU = std::max(1, std::min(8, (160 * 1024) / (4 * kWaveLdsBytes + kLdsSlack + 1024)));
-        const int full = std::max(1, std::min(tune > 0 ? tune : 256 * kBlocksPerCU * eighths / 8, (a.list_stride + 3) / 4));
+        const int full = std::max(1, std::min(tune > 0 ? tune : 256 * kBlocksPerCU * sixteenths / 16, (a.list_stride + 3) / 4));
         const int blocks = a.ref_mode ? full : predicted_blocks(c->hist_exact_chunks, full);
         if (a.ref_mode) hipLaunchKernelGGL(k_dp_ref, dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);
@@ -482,7 +482,11 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         // twice as long every time a retry (again on probation) fails.
         int nb = 0;
         for (int k = 0; k < kNumBandClasses; ++k) nb += c->h_counters[kCntClass0 + kBandClass0 + k];
-        if (c->band_cooldown > 0) {
+        static const bool aid = getenv("STRKIT_AMD_DBG") && atoi(getenv("STRKIT_AMD_DBG")) != 0;
+        if (aid) {   // profiling runs with parts of the kernels switched off (wrong scores by design): keep the band on
+            c->band_cooldown = 0;
+            c->band_probation = false;
+        } else if (c->band_cooldown > 0) {
             --c->band_cooldown;
         } else if (nb >= 64) {
             if (2 * c->h_counters[kCntBandFallback] > nb) {

@@ -121,7 +121,10 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         return BWD ? x.pad + ncols - j : x.pad + j - 1;   // always inside the padded array (BandLayout)
     };
     int Ha[D], Hb[D];
+    int Hsave[BWD ? D : 1];   // backward pass: the lane's last row
     unsigned sel[NQ];
+#pragma unroll
+    for (int k = 0; k < (BWD ? D : 1); ++k) Hsave[k] = 0;
 #pragma unroll
     for (int k = 0; k < D; ++k) Ha[k] = g0(-x.lig + d0 + k);
     const int jb0 = 1 - x.lig + d0;                   // column of slot 0 at the row of step 0 (step t: jb0 + t)
@@ -213,11 +216,9 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     if ((TT) == forkT) {                                                                           \
         const int jb = jb0 + (TT);                      /* column of slot 0 at that step's row */  \
         if (BWD) {                                                                                 \
-            /* last row: slot k is reversed column jb + k, i.e. db node ndb - (jb + k) */           \
-            _Pragma("unroll") for (int k = 0; k < D; ++k) {                                        \
-                const int jp = jb + k, idx = ncols - jp - cmin;                                    \
-                if (jp >= 0 && jp <= ncols && idx >= 0 && idx < ncol) b0col[idx] = (short)V[k];    \
-            }                                                                                      \
+            /* last row of this lane: put aside (every lane reaches it at a step of its own; the store into the column   \
+               array, with its bounds checks per slot, runs once behind the loop for all lanes together) */               \
+            _Pragma("unroll") for (int k = 0; k < D; ++k) Hsave[k] = V[k];                         \
             forkT = 0x7fffffff;                                                                    \
         } else {                                                                                   \
             const short* bc = b0col + (jb - cmin);                                                 \
@@ -260,6 +261,15 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         }
     }
     STRK_BAND_FORK(Ha, T - 1)
+    if (BWD && nrows > 0) {
+        // last row: slot k is reversed column jb + k, i.e. db node ndb - (jb + k)
+        const int jb = jb0 + nrows - 1 + x.lig;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int jp = jb + k, idx = ncols - jp - cmin;
+            if (jp >= 0 && jp <= ncols && idx >= 0 && idx < ncol) b0col[idx] = (short)Hsave[k];
+        }
+    }
 #undef STRK_BAND_STEP
 #undef STRK_BAND_FORK
 }
@@ -292,7 +302,11 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
 #ifdef STRK_PHASE_TIMING
     unsigned long long tphase = __builtin_readcyclecounter();
 #endif
-    const int lig = lane & (G - 1);
+    int lig_ = lane & (G - 1);
+    // (opaque per chunk: what a pass derives from the lane index and the class's constants — sixteen clamped row-0 values of
+    // the backward band, for one — would otherwise be hoisted out of the chunk loop and held, or spilled, across both passes)
+    asm volatile("" : "+v"(lig_));
+    const int lig = lig_;
     const int grp = lane / G;
     const bool first = lig == 0, last = lig == G - 1;
     uint8_t* const Lg = Lw + grp * lay.group_bytes;
@@ -317,7 +331,8 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
         motif += q2.z;
     }
     const int ndb = nfl + ntr + nfr;
-    const BandGeo geo = band_geometry(nfl, ntr, nfr, m, lo, max(n, 1));
+    // (k_plan listed the item under this class: band_geometry's search over the classes need not be repeated)
+    const BandGeo geo = band_geometry_of_class(BC, nfl, ntr, m, lo, max(n, 1));
     const int rowsP = act ? nfl + (lo + n - 1) * m : 0;
     const int rowsT = act ? nfr : 0;
     const bool dbBeg = a.end_flags & 1, dbEnd = a.end_flags & 2, cBeg = a.end_flags & 4, cEnd = a.end_flags & 8;
@@ -387,18 +402,22 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
             for (int k = lig; k < m; k += G) motifL[k] = (uint8_t)(8 * motifL[k]);   // (own entries only)
         } else {
             // (as far as the longest item of the wave reads: every byte a step can fetch is a valid table offset)
+            // Three stretches, a loop each: G - 1 null rows in front, the flank rows (their selector bytes), the motif rows
+            // (phase kept per lane), null rows behind.
             const int lenP = wave_max_over_groups(rowsP) + 2 * (G - 1) + 4;
-            const int gstep = G % m;
-            int ph = (lig - (G - 1) - nfl) % m;
-            if (ph < 0) ph += m;
-            for (int idx = lig; idx < lenP; idx += G) {
-                const int row = idx - (G - 1);
-                int sym = kNullSym;
-                if (row >= 0 && row < rowsP) sym = row < nfl ? kBandTblClass0 + selb[lay.pad + row] : motifL[ph];
-                cp[idx] = (uint8_t)(8 * sym);
-                ph += gstep;
-                if (ph >= m) ph -= m;
+            for (int idx = lig; idx < G - 1; idx += G) cp[idx] = (uint8_t)(8 * kNullSym);
+            uint8_t* const cpr = cp + (G - 1);          // cpr[row]
+            for (int row = lig; row < min(nfl, rowsP); row += G) cpr[row] = (uint8_t)(8 * (kBandTblClass0 + selb[lay.pad + row]));
+            {
+                const int gstep = G % m;
+                int ph = lig % m;
+                for (int row = nfl + lig; row < rowsP; row += G) {
+                    cpr[row] = (uint8_t)(8 * motifL[ph]);
+                    ph += gstep;
+                    if (ph >= m) ph -= m;
+                }
             }
+            for (int row = rowsP + lig; row < lenP - (G - 1); row += G) cpr[row] = (uint8_t)(8 * kNullSym);
         }
         const int lenT = wave_max_over_groups(rowsT) + 2 * (G - 1) + 4;
         for (int idx = lig; idx < lenT; idx += G) {
@@ -409,7 +428,12 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
         }
     }
     wave_lds_sync();
-    for (int k = lig; k < lay.maxcol; k += G) b0col[k] = (short)kBandNeg16;
+    {   // (two columns per store; as many as the widest item of the wave has: ncol = (n - 1) m + band width)
+        constexpr unsigned kNeg2 = ((unsigned)(unsigned short)(short)kBandNeg16) * 0x00010001u;
+        const int nc2 = min(lay.maxcol, wave_max_over_groups(act ? geo.ncol : 0) + 1) >> 1;
+        unsigned* const b2 = reinterpret_cast<unsigned*>(b0col);
+        for (int k = lig; k <= nc2; k += G) if (2 * k < lay.maxcol) b2[k] = kNeg2;
+    }
     wave_lds_sync();
     nextB();
     STRK_PHASE(2);

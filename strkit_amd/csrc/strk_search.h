@@ -198,6 +198,26 @@ STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, 
     return b;
 }
 
+// The geometry of an item that band_geometry has already put into class `cls` (k_plan did; the band kernel works on that class's
+// list): the same numbers without the search over the classes, in 32-bit arithmetic (the class limits bound every length).
+STRK_HD BandGeo band_geometry_of_class(int32_t cls, int32_t nfl, int32_t ntr, int32_t m, int32_t lo, int32_t n) {
+    BandGeo b;
+    const int32_t e_lo = ntr - (lo + n - 1) * m, e_hi = ntr - lo * m;
+    const int32_t span_lo = e_lo < 0 ? e_lo : 0, span_hi = e_hi > 0 ? e_hi : 0;
+    const int32_t wd = band_class_wd(cls);
+    const int32_t extra = wd - (span_hi - span_lo + 1);
+    b.ok = 1;
+    b.cls = cls;
+    b.G = band_class_G(cls);
+    b.wd = wd;
+    b.dlo = span_lo - extra / 2;
+    b.bwd = wd;
+    b.bdlo = -(wd / 2);
+    b.cmin = nfl + lo * m + b.dlo;
+    b.ncol = (n - 1) * m + wd;
+    return b;
+}
+
 // (32-bit arithmetic: band_ub is only asked about items band_geometry accepted, whose lengths are bounded by the class limits)
 STRK_HD int32_t band_diag_len(int32_t nc, int32_t ndb, int32_t d) {
     const int32_t v = d >= 0 ? (nc < ndb - d ? nc : ndb - d) : (nc + d < ndb ? nc + d : ndb);
