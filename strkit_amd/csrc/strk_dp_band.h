@@ -213,12 +213,16 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     // the fork-row work of step TT on that step's output row V.  It runs at the head of the NEXT step, so that a step
     // itself is one basic block from its LDS byte loads to their uses.
 #define STRK_BAND_FORK(V, TT)                                                                      \
-    if ((TT) == forkT) {                                                                           \
+    /* (backward: the body is a dozen register copies, which the compiler would predicate and execute at EVERY step; the     \
+       wave-uniform test in front makes it a real branch) */                                                                 \
+    if ((!BWD || __builtin_amdgcn_ballot_w64((TT) == forkT) != 0) && (TT) == forkT) {              \
         const int jb = jb0 + (TT);                      /* column of slot 0 at that step's row */  \
         if (BWD) {                                                                                 \
             /* last row of this lane: put aside (every lane reaches it at a step of its own; the store into the column   \
                array, with its bounds checks per slot, runs once behind the loop for all lanes together) */               \
-            _Pragma("unroll") for (int k = 0; k < D; ++k) Hsave[k] = V[k];                         \
+            _Pragma("unroll") for (int k = 0; k < D; ++k)                                          \
+                asm volatile("v_mov_b32 %0, %1" : "+v"(Hsave[k]) : "v"(V[k]));   /* (a plain copy makes the allocator merge the   \
+                    save array with the row arrays and copy a whole row per pair of steps instead) */                      \
             forkT = 0x7fffffff;                                                                    \
         } else {                                                                                   \
             const short* bc = b0col + (jb - cmin);                                                 \
