@@ -9,13 +9,14 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 ARGS="bench.py --no-cpu-baseline --no-extras --no-e2e --steps 16 --warmup 4 $EXTRA"   # EXTRA: e.g. "--config 3"
 echo "[prof $TAG] kernel trace, pipelined"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o b -- python3 $ARGS > $OUT/trace.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o b -- python3 $ARGS > $OUT/trace.log 2>&1
 echo "[prof $TAG] kernel trace, one call at a time"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_p1 -o b -- python3 $ARGS --pipeline 1 > $OUT/trace_p1.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_p1 -o b -- python3 $ARGS --pipeline 1 > $OUT/trace_p1.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   echo "[prof $TAG] pmc $set"
-  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$tag -o b -- python3 $ARGS --pipeline 1 > $OUT/pmc_$tag.log 2>&1 || echo "pmc $set failed"
+  # (a pass that does not come back — seen twice on this pool, after the program had finished — is cut off, the others still count)
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$tag -o b -- python3 $ARGS --pipeline 1 > $OUT/pmc_$tag.log 2>&1 || echo "pmc $set failed"
 done
 grep -h "^{\"metric" $OUT/trace.log | cut -c1-300
 python3 tools/prof_summary.py $OUT $OUT/summary.json $OUT/pmc_summary.json > $OUT/summary.txt 2>&1 || true
