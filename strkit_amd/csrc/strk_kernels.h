@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     __shared__ int s_cnt[kNumLists];
     __shared__ int s_base[kNumLists];
     __shared__ unsigned long long s_cells, s_bytes_band, s_bytes_exact, s_bytes_wide, s_bytes_long;
-    __shared__ unsigned long long s_key[256];
+    __shared__ __attribute__((aligned(16))) unsigned s_key[256];
+    __shared__ int s_below[kNumBandClasses];   // band items of this block in band classes below c
     __shared__ int s_lb[4];   // loci per motif-length bucket (counted at a locus's first read)
     if (threadIdx.x < 4) s_lb[threadIdx.x] = 0;
     if (threadIdx.x < kNumLists) s_cnt[threadIdx.x] = 0;
@@ -305,8 +306,15 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     if (threadIdx.x < kNumLists) {
         const int c = threadIdx.x;
         s_base[c] = s_cnt[c] ? atomicAdd(&a.counters[kCntClass0 + c], s_cnt[c]) : 0;
-        s_cnt[c] = 0;
     }
+    __syncthreads();
+    if (threadIdx.x < kNumBandClasses) {
+        int below = 0;
+        for (int k = 0; k < (int)threadIdx.x; ++k) below += s_cnt[kBandClass0 + k];
+        s_below[threadIdx.x] = below;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumLists) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x < 4 && s_lb[threadIdx.x]) atomicAdd(&a.counters[kCntLociB + threadIdx.x], s_lb[threadIdx.x]);
     if (threadIdx.x == 0 && s_cells) {
         atomicAdd(a.cells, s_cells);
@@ -321,16 +329,21 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     // steps than the items need; sorted by rows: 4 %).  rank = items of this block that sort before mine.
     int band_rank = 0;
     {
-        const unsigned long long mine = band_list >= 0 ? ((unsigned long long)(band_list - kBandClass0) << 60) |
-                                                           ((unsigned long long)(nfl + (lo + n - 1) * m) << 10) | threadIdx.x
-                                                       : ~0ull;
+        // 32-bit keys (class | prefix rows | thread): items that sort before mine = keys below mine, four per LDS read; those of
+        // the lower classes are the same number for every item of a class (s_below)
+        const unsigned mine = band_list >= 0 ? ((unsigned)(band_list - kBandClass0) << 28) |
+                                                   ((unsigned)min(nfl + (lo + n - 1) * m, (1 << 20) - 1) << 8) | threadIdx.x
+                                             : ~0u;
         s_key[threadIdx.x] = mine;
         __syncthreads();
-        if (band_list >= 0)
-            for (int q = 0; q < 256; ++q) {
-                const unsigned long long o = s_key[q];
-                band_rank += (o < mine && (o >> 60) == (mine >> 60)) ? 1 : 0;
+        if (band_list >= 0) {
+            const uint4* k4 = reinterpret_cast<const uint4*>(s_key);
+            for (int q = 0; q < 64; ++q) {
+                const uint4 o = k4[q];
+                band_rank += (o.x < mine) + (o.y < mine) + (o.z < mine) + (o.w < mine);
             }
+            band_rank -= s_below[band_list - kBandClass0];
+        }
     }
     for (int k0 = 0; k0 < n; k0 += kTableMax) {
         const int nn = min(kTableMax, n - k0);

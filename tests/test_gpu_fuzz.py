@@ -2,6 +2,7 @@
 A few seconds by default; STRK_FUZZ_SECONDS=300 python -m pytest tests/test_gpu_fuzz.py -m gpu for a soak run
 (the seed is printed on failure)."""
 import os
+import sys
 import time
 
 import numpy as np
@@ -105,6 +106,7 @@ def test_random_batches_and_options_match_the_oracle(gpu_ctx):
     seed = int(os.environ.get("STRK_FUZZ_SEED", default_seed))
     rng = np.random.default_rng(seed)
     t0, cases, reads, pairs, loci = time.time(), 0, 0, 0, 0
+    t_note = time.time()
     try:
         while time.time() - t0 < SECONDS or cases < 12:
             if cases % 4 == 3:
@@ -116,6 +118,10 @@ def test_random_batches_and_options_match_the_oracle(gpu_ctx):
             cases += 1
             if cases % 40 == 0:
                 print(f"[fuzz seed {seed}] {cases} cases so far", flush=True)
+            if time.time() - t_note > 60:   # a soak run under pytest's capture must not look hung (the real stderr is not captured)
+                t_note = time.time()
+                sys.__stderr__.write(f"[fuzz seed {seed}] {cases} cases, {time.time() - t0:.0f} s\n")
+                sys.__stderr__.flush()
     except AssertionError as e:
         raise AssertionError(f"fuzz seed {seed}, case {cases}: {e}") from e
     print(f"\n[fuzz seed {seed}] {cases} cases, {reads} reads, {pairs} realignments, {loci} reference-side loci in {time.time() - t0:.1f} s")
