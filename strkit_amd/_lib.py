@@ -16,6 +16,7 @@ STRK_TIE_FIRST, STRK_TIE_LAST = 0, 1
 STRK_NARROW_NONE = 0
 STRK_I16_CELL_MAY_SATURATE, STRK_I16_SCORE_SATURATES = 1, 2
 STRK_E_EMPTY = -61
+STRK_E_INVALID, STRK_E_NOMEM, STRK_E_DEVICE, STRK_E_NODEV = -22, -12, -5, -19
 
 _u8p = C.POINTER(C.c_uint8)
 _i32p = C.POINTER(C.c_int32)

@@ -36,6 +36,16 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.strk_version()
 
 
+def test_host_register_rejects_bad_arguments_before_touching_the_device():
+    lib = _lib.load(build=False)
+    assert lib.strk_host_register(None, 16) == _lib.STRK_E_INVALID
+    assert b"strk_host_register" in lib.strk_last_error()
+    buf = (C.c_uint8 * 16)()
+    assert lib.strk_host_register(C.cast(buf, C.c_void_p), 0) == _lib.STRK_E_INVALID
+    assert lib.strk_host_unregister(None) == _lib.STRK_E_INVALID
+    assert lib.strk_host_is_pinned(None, 16) == 0
+
+
 def test_init_fails_loudly_without_a_gpu_and_errors_are_reported():
     import torch
     if torch.cuda.is_available():
