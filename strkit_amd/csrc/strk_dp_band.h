@@ -158,12 +158,17 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         const unsigned long long v = *reinterpret_cast<const __attribute__((address_space(3))) unsigned long long*>(tbl + sym8);
         return make_uint2((unsigned)v, (unsigned)(v >> 32));
     };
-    int rowi = -x.lig, ph = 0;
+    // FLY: the lane's row symbols come from one running LDS address.  The flank symbols are staged right-aligned in front of the
+    // motif (null rows in front of them: lane l starts G - 1 - ... rows before row 0), so the address runs from the null rows
+    // through the flank into the motif without a test, and wraps to the motif's start at its end (add, compare, select per row;
+    // the phase counter with its two compares and two selects per row cost a tenth of the wide classes' steps).
+    lds_cu8 pfly = (lds_cu8)(x.flL + 256 - x.nfl - x.lig);
+    lds_cu8 const motBase = (lds_cu8)x.motifL;
+    lds_cu8 const motEnd = motBase + x.m;
     auto next_sym = [&]() -> unsigned {
-        unsigned sym = 8 * kNullSym;
-        if (rowi >= 0) sym = rowi < x.nfl ? x.flL[rowi] : x.motifL[ph];
-        if (rowi >= x.nfl) { ++ph; if (ph == x.m) ph = 0; }
-        ++rowi;
+        const unsigned sym = *pfly;
+        pfly += 1;
+        if (pfly == motEnd) pfly = motBase;
         return sym;
     };
     // row words are fetched two steps ahead (wordE / wordO: even / odd steps).  Every LDS byte is loaded at the head of a
@@ -401,7 +406,11 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
         // row symbols index the row-word table: kBandTblClass0 + class for a flank base (its selector byte), the
         // encoded symbol for a motif base
         if (FLY) {
-            for (int k = lig; k < 256; k += G) cp[k] = (uint8_t)(8 * (k < nfl ? kBandTblClass0 + selb[lay.pad + k] : kNullSym));
+            // flank rows right-aligned in front of the motif symbols, null rows in front of them (band_pass, next_sym)
+            for (int k = lig; k < 256; k += G) {
+                const int row = k - (256 - nfl);
+                cp[k] = (uint8_t)(8 * (row >= 0 ? kBandTblClass0 + selb[lay.pad + row] : kNullSym));
+            }
             wave_lds_sync();
             for (int k = lig; k < m; k += G) motifL[k] = (uint8_t)(8 * motifL[k]);   // (own entries only)
         } else {

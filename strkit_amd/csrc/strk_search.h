@@ -138,7 +138,7 @@ struct BandGeo {
 // read needs follows its motif length: motifs of up to 4 bases leave a band of 96 as much slack as longer ones have in 128,
 // motifs of ~17 need 330 diagonals at W = 8 (BASELINE config 4's long motifs: 384 instead of 512).
 // Per-class limits (what the class's LDS layout holds: class c lives in the layout of class c & 3).  Lane counts of 32 and 64
-// generate the forward row symbols on the fly (left flank <= 255 rows from LDS, then the motif with a running phase).
+// generate the forward row symbols on the fly (left flank <= 192 rows from LDS, then the motif, one running address).
 constexpr int kNumBandClasses = 8;
 STRK_HD constexpr int band_class_layout(int c) { return c & 3; }
 STRK_HD constexpr int band_class_G(int c) { return 8 << (c & 3); }
@@ -152,6 +152,7 @@ STRK_HD constexpr bool band_class_fly(int c) { return (c & 3) >= 2; }
 STRK_HD constexpr bool band_class_lmax(int c) { return (c & 3) >= 1; }
 STRK_HD constexpr bool band_class_wide_kernel(int c) { return (c & 3) >= 2; }   // k_dp_band_wide's classes
 constexpr int kBandMaxFlank = 127;
+constexpr int kBandFlyMaxFlank = 192;   // on-the-fly rows: 256 staged bytes hold the left flank behind the 63 null rows of the last lane
 constexpr int kBandRowSlack = 96;    // prefix rows a band item may have beyond |db|
 constexpr int kBandNarrowSlack = 22; // diagonals a 12-diagonal class keeps free on each side of the candidates' span, at least
 
@@ -177,7 +178,7 @@ STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, 
         const int64_t slack = (c >= 4 && smin < kBandNarrowSlack) ? kBandNarrowSlack : smin;
         if (span_hi - span_lo + 1 + 2 * slack > w) continue;
         if (ndb > band_max_db(c) || (int64_t)(n - 1) * m + w > band_max_col(c) || rows > band_max_db(c) + kBandRowSlack) continue;
-        if (band_class_fly(c) && nfl > 255) continue;
+        if (band_class_fly(c) && nfl > kBandFlyMaxFlank) continue;
         cls = c;
     }
     if (cls < 0) return b;
