@@ -50,9 +50,10 @@ UNIT_LOCI = 1000                    # one instance of a BASELINE config 2 / 3 ba
 # the five DP kernels of a call: (name, strk_stats field with its HIP-event duration)
 DP_KERNELS = (("k_dp_band", "band_kernel_ms"), ("k_dp_band_wide", "band_wide_kernel_ms"), ("k_dp_all", "dp_kernel_ms"),
               ("k_dp_long", "long_kernel_ms"), ("k_dp_generic", "generic_kernel_ms"))
-SUB_CONFIGS = {3: (10000, "cfg3 shape: 10 000 loci x 20 ONT-error reads, motif 2-20 bp"),
-               4: (21250, "cfg4 shape, one GPU's eighth of the whole-genome catalog: 21 250 loci x 30 HiFi reads, 70 % motifs 1-6 bp / 30 % 7-20 bp"),
-               5: (250, "cfg5 shape, expansion stress: 250 loci x 40 reads, motif 1-6 bp, 50-2 000 copies")}
+SUB_CONFIGS = {"cfg3": (3, 10000, "cfg3 shape: 10 000 loci x 20 ONT-error reads, motif 2-20 bp"),
+               "cfg4": (4, 21250, "cfg4 shape, one GPU's eighth of the whole-genome catalog: 21 250 loci x 30 HiFi reads, 70 % motifs 1-6 bp / 30 % 7-20 bp"),
+               "cfg5": (5, 250, "cfg5 shape, expansion stress, one GPU's eighth: 250 loci x 40 reads, motif 1-6 bp, 50-2 000 copies"),
+               "cfg5_all": (5, 2000, "cfg5, the whole configuration on this GPU: 2 000 loci x 40 reads, motif 1-6 bp, 50-2 000 copies")}
 
 
 def _gen_worker(args):
@@ -289,8 +290,8 @@ def main() -> None:
             batches = make_batches(a.config, n_loci, max(1, a.batches), rank, pool)
         sub_batches = {}
         if rank == 0 and a.gpus == 1 and not a.no_extras and not a.no_configs and not a.strong and a.config == 2 and a.loci is None:
-            for c, (nl, _) in SUB_CONFIGS.items():     # the other single-GPU configurations of BASELINE.json, two batches each
-                sub_batches[c] = make_batches(c, nl, 2, 7, pool)
+            for name, (c, nl, _) in SUB_CONFIGS.items():     # the other single-GPU configurations of BASELINE.json, two batches each
+                sub_batches[name] = make_batches(c, nl, 2, 7, pool)
     e2e_data = None
     if rank == 0 and a.gpus == 1 and not a.no_e2e and not a.strong:
         # files for the end-to-end sub-result: north_star's "10 000 loci x 30x HiFi reads genotyped end-to-end", ~15 kb reads
@@ -607,9 +608,10 @@ def main() -> None:
 
     # ---- the other single-GPU configurations of BASELINE.json, timed by this same run (rank 0 of a one-GPU default run) ----
     configs_out = {}
-    for c in sorted(sub_batches):
-        progress(f"extras: config {c}")
-        bl_c = sub_batches[c]
+    for name in sorted(sub_batches):
+        c = SUB_CONFIGS[name][0]
+        progress(f"extras: {name}")
+        bl_c = sub_batches[name]
         # contexts of its own: the band of a shared context may be in a cool-down after another configuration's noisy reads
         for cx in ctxs:
             cx.close()
@@ -644,8 +646,8 @@ def main() -> None:
         # (the one-at-a-time leg's last call ran batch 1 into out_c[D])
         roof_c = roofline_block(c, ac_c, iso_c, ac_c["n"], True)
         dp_ms_c = sum(iso_c[k] for k, _ in DP_KERNELS)
-        configs_out[f"cfg{c}"] = {
-            "workload": SUB_CONFIGS[c][1], "loci_per_step": bl_c[0].n_loci, "reads_per_step": bl_c[0].n_reads,
+        configs_out[name] = {
+            "workload": SUB_CONFIGS[name][2], "loci_per_step": bl_c[0].n_loci, "reads_per_step": bl_c[0].n_reads,
             "value": ac_c["reads"] / el_c, "unit": "reads/s", "steps": k_steps, "ms_per_step": el_c / k_steps * 1e3, "calls_in_flight": D,
             "one_call_at_a_time": {"value": v1c, "ms_per_step": ms1c},
             "window": sorted(ac_c["windows"]), "band_reads_per_step": ac_c["band"] / ac_c["n"],
