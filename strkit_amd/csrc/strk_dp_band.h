@@ -144,11 +144,13 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     int forkT = (!BWD && nEff > 0) ? fork0 - 1 + x.lig : 0x7fffffff;
     if (BWD && nrows > 0) forkT = nrows - 1 + x.lig;
     int forkIdx = 0;
-    // classes of band_class_lmax: running maximum of the last column over the in-band rows.  Right of column |db|
-    // the pads replicate G(r, |db|), so from row |db| - dhi on the last lane's last slot holds that value.
+    // classes of band_class_lmax: running maximum, over the rows from 1 on, of (last slot of the last lane) - g * row.  Right of
+    // column |db| the pads replicate G(r, |db|), so from row |db| - dhi on that slot holds the last column's value: an alignment
+    // that ends there.  Before that row it holds the band's rightmost cell (r, j < |db|), and G(r, j) - g r - g |db| =
+    // H(r, j) - g (|db| - j) is the score of a real alignment too (gap the rest of the window, end in the last column), so it
+    // may take part: S_band stays a lower bound, and the test that used to exclude those rows costs two instructions per step.
     int lastmax = kNegInf;
     int gr = -g * x.lig;                               // g * (row finished before step 0): LMAX only
-    const int grFirst = g * max(1, ncols - dhi_);
     // row symbols (8 * table index): staged in LDS with G-1 null rows in front (this lane's row at step t is psym[t]), or
     // generated two steps ahead from the left flank and the motif phase (long windows).  psym / pnb are running LDS
     // addresses, advanced once per pair of steps; the steps read at constant offsets from them.
@@ -209,7 +211,8 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         asm volatile("" : "+v"(nb), "+v"(sym2));                                                   \
         if (LMAX && !BWD) {                                                                        \
             gr += g;                                                                               \
-            lastmax = (gr >= grFirst) ? max(lastmax, houtL - gr) : lastmax;                        \
+            lastmax = max(lastmax, houtL - gr);                                                    \
+            if ((TT) == G - 2) lastmax = kNegInf;   /* (scalar test) the last lane has just finished row 0 */ \
         }                                                                                          \
         _Pragma("unroll") for (int q = 0; q + 1 < NQ; ++q) sel[q] = __builtin_amdgcn_alignbyte(sel[q + 1], sel[q], 1); \
         sel[NQ - 1] = __builtin_amdgcn_alignbyte(nb, sel[NQ - 1], 1);                              \
