@@ -78,6 +78,7 @@ struct BandCtx {
     const uint8_t* flL;    // on-the-fly forward rows: 256 left-flank symbols, 256 motif symbols
     const uint8_t* motifL;
     int nfl, m;
+    int flyP;              // on-the-fly rows: the whole number of motif copies (in bytes) the running address is taken back by
 };
 
 // min over the (at most eight) groups of a wave of a value that is uniform inside each group
@@ -154,38 +155,31 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     // row symbols (8 * table index): staged in LDS with G-1 null rows in front (this lane's row at step t is psym[t]), or
     // generated two steps ahead from the left flank and the motif phase (long windows).  psym / pnb are running LDS
     // addresses, advanced once per pair of steps; the steps read at constant offsets from them.
-    lds_cu8 psym = (lds_cu8)(rowsym + (G - 1) - x.lig);
+    // FLY (long windows): the same running address over 256 flank + 256 motif symbols — the flank staged right-aligned in front of
+    // the motif (null rows in front of it: lane l starts l rows before row 0), the motif repeated cyclically behind it — so the
+    // address runs from the null rows through the flank into the motif without a test and is taken back by a whole number of
+    // motif copies (x.flyP) once per PAIR of steps when it has passed them (add, compare, select per pair; a phase counter per
+    // row with two compares and two selects cost a tenth of the wide classes' steps).
+    lds_cu8 psym = FLY ? (lds_cu8)(x.flL + 256 - x.nfl - x.lig) : (lds_cu8)(rowsym + (G - 1) - x.lig);
+    lds_cu8 const flyEnd = (lds_cu8)x.motifL + x.flyP;
     lds_cu8 const tbl = (lds_cu8)x.tbl;
     auto row_word = [&](unsigned sym8) -> uint2 {
         const unsigned long long v = *reinterpret_cast<const __attribute__((address_space(3))) unsigned long long*>(tbl + sym8);
         return make_uint2((unsigned)v, (unsigned)(v >> 32));
     };
-    // FLY: the lane's row symbols come from one running LDS address.  The flank symbols are staged right-aligned in front of the
-    // motif (null rows in front of them: lane l starts G - 1 - ... rows before row 0), so the address runs from the null rows
-    // through the flank into the motif without a test, and wraps to the motif's start at its end (add, compare, select per row;
-    // the phase counter with its two compares and two selects per row cost a tenth of the wide classes' steps).
-    lds_cu8 pfly = (lds_cu8)(x.flL + 256 - x.nfl - x.lig);
-    lds_cu8 const motBase = (lds_cu8)x.motifL;
-    lds_cu8 const motEnd = motBase + x.m;
-    auto next_sym = [&]() -> unsigned {
-        const unsigned sym = *pfly;
-        pfly += 1;
-        if (pfly == motEnd) pfly = motBase;
-        return sym;
-    };
     // row words are fetched two steps ahead (wordE / wordO: even / odd steps).  Every LDS byte is loaded at the head of a
     // step and used at its end, in the same basic block: the compiler then knows that ds_read_u8 zero-extends (a value that
     // crosses the fork-row branch would be masked again).
     uint2 wordE, wordO;
-    if (FLY) { wordE = row_word(next_sym()); wordO = row_word(next_sym()); }
-    else { wordE = row_word(psym[0]); wordO = row_word(psym[1]); }
+    wordE = row_word(psym[0]);
+    wordO = row_word(psym[1]);
     // class byte entering the lane's window after step t: column jb0 + t + D
     lds_cu8 pnb = (lds_cu8)(x.selb + col_addr(jb0 + D)) - (BWD ? 1 : 0);
 #define STRK_BAND_STEP(SRC, DST, TT, ODD, EDGE)                                                    \
     {                                                                                              \
         STRK_BAND_FORK(SRC, (TT) - 1)                                                              \
         const uint2 word = (ODD) ? wordO : wordE;                                                  \
-        unsigned sym2 = FLY ? next_sym() : (unsigned)psym[2 + (ODD)];   /* row of step TT + 2 */   \
+        unsigned sym2 = (unsigned)psym[2 + (ODD)];                      /* row of step TT + 2 */   \
         unsigned nb = pnb[BWD ? 1 - (ODD) : (ODD)];                                                \
         int leftEdge, keepU = 0;                                                                   \
         if (EDGE) {                                                                                \
@@ -252,7 +246,9 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     // runs of plain pairs and runs of boundary pairs alternate, each run a loop of its own (one loop with both forms in
     // its body makes the compiler copy the two row arrays once per pair)
     auto advance = [&]() {
-        if (!FLY) { psym += 2; asm volatile("" : "+v"(psym)); }
+        psym += 2;
+        if (FLY && psym >= flyEnd) psym -= x.flyP;
+        asm volatile("" : "+v"(psym));
         pnb += BWD ? -2 : 2;
         asm volatile("" : "+v"(pnb));
     };
@@ -409,13 +405,15 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
         // row symbols index the row-word table: kBandTblClass0 + class for a flank base (its selector byte), the
         // encoded symbol for a motif base
         if (FLY) {
-            // flank rows right-aligned in front of the motif symbols, null rows in front of them (band_pass, next_sym)
+            // flank rows right-aligned in front of the motif symbols, null rows in front of them (band_pass)
             for (int k = lig; k < 256; k += G) {
                 const int row = k - (256 - nfl);
                 cp[k] = (uint8_t)(8 * (row >= 0 ? kBandTblClass0 + selb[lay.pad + row] : kNullSym));
             }
             wave_lds_sync();
             for (int k = lig; k < m; k += G) motifL[k] = (uint8_t)(8 * motifL[k]);   // (own entries only)
+            wave_lds_sync();
+            for (int k = m + lig; k < 256; k += G) motifL[k] = motifL[k % m];       // the motif, cyclically, up to the region's end
         } else {
             // (as far as the longest item of the wave reads: every byte a step can fetch is a valid table offset)
             // Three stretches, a loop each: G - 1 null rows in front, the flank rows (their selector bytes), the motif rows
@@ -459,6 +457,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     asm volatile("" : "+v"(x.notFirst), "+v"(x.notLast));   // plain AND masks: operands of the DPP shifts, not selects
     x.pad = lay.pad; x.maxidx = lay.sel_len - 1; x.ndb = ndb;
     x.flL = cp; x.motifL = motifL; x.nfl = nfl; x.m = m;
+    x.flyP = FLY ? ((256 - 4) / m) * m : 0;   // (a pair of steps reads up to three bytes behind the address: kBandFlyMaxMotif)
     const bool run = act && !fallback && geo.ok;
     const int nEff = run ? n : 0;
     // backward pass (reversed right flank x reversed window), then forward pass with the fork rows

@@ -152,6 +152,7 @@ STRK_HD constexpr bool band_class_fly(int c) { return (c & 3) >= 2; }
 STRK_HD constexpr bool band_class_lmax(int c) { return (c & 3) >= 1; }
 STRK_HD constexpr bool band_class_wide_kernel(int c) { return (c & 3) >= 2; }   // k_dp_band_wide's classes
 constexpr int kBandMaxFlank = 127;
+constexpr int kBandFlyMaxMotif = 126;   // ... and the motif at least twice (the running address is taken back by whole copies)
 constexpr int kBandFlyMaxFlank = 192;   // on-the-fly rows: 256 staged bytes hold the left flank behind the 63 null rows of the last lane
 constexpr int kBandRowSlack = 96;    // prefix rows a band item may have beyond |db|
 constexpr int kBandNarrowSlack = 22; // diagonals a 12-diagonal class keeps free on each side of the candidates' span, at least
@@ -178,7 +179,7 @@ STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, 
         const int64_t slack = (c >= 4 && smin < kBandNarrowSlack) ? kBandNarrowSlack : smin;
         if (span_hi - span_lo + 1 + 2 * slack > w) continue;
         if (ndb > band_max_db(c) || (int64_t)(n - 1) * m + w > band_max_col(c) || rows > band_max_db(c) + kBandRowSlack) continue;
-        if (band_class_fly(c) && nfl > kBandFlyMaxFlank) continue;
+        if (band_class_fly(c) && (nfl > kBandFlyMaxFlank || m > kBandFlyMaxMotif)) continue;
         cls = c;
     }
     if (cls < 0) return b;
