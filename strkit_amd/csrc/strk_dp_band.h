@@ -150,8 +150,8 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     // that ends there.  Before that row it holds the band's rightmost cell (r, j < |db|), and G(r, j) - g r - g |db| =
     // H(r, j) - g (|db| - j) is the score of a real alignment too (gap the rest of the window, end in the last column), so it
     // may take part: S_band stays a lower bound, and the test that used to exclude those rows costs two instructions per step.
+    // Kept as M = max_r (G(r, .) - g r) + g * (row just finished): M <- max(M + g, G(row, .)).
     int lastmax = kNegInf;
-    int gr = -g * x.lig;                               // g * (row finished before step 0): LMAX only
     // row symbols (8 * table index): staged in LDS with G-1 null rows in front (this lane's row at step t is psym[t]), or
     // generated two steps ahead from the left flank and the motif phase (long windows).  psym / pnb are running LDS
     // addresses, advanced once per pair of steps; the steps read at constant offsets from them.
@@ -204,8 +204,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
            this block only: their uses may be moved below the next fork-row branch) */                  \
         asm volatile("" : "+v"(nb), "+v"(sym2));                                                   \
         if (LMAX && !BWD) {                                                                        \
-            gr += g;                                                                               \
-            lastmax = max(lastmax, houtL - gr);                                                    \
+            lastmax = max(lastmax + g, houtL);      /* (kept shifted by g * row: add and max per step) */ \
             if ((TT) == G - 2) lastmax = kNegInf;   /* (scalar test) the last lane has just finished row 0 */ \
         }                                                                                          \
         _Pragma("unroll") for (int q = 0; q + 1 < NQ; ++q) sel[q] = __builtin_amdgcn_alignbyte(sel[q + 1], sel[q], 1); \
@@ -232,7 +231,7 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
             _Pragma("unroll") for (int k = 0; k < D; k += 2)                                       \
                 acc = max(max(acc, V[k] + (int)bc[k]), V[k + 1] + (int)bc[k + 1]);                 \
             atomicMax(&comb[forkIdx], acc);                                                        \
-            if (LMAX && x.last) lmaxA[forkIdx] = lastmax;                                          \
+            if (LMAX && x.last) lmaxA[forkIdx] = lastmax - g * ((TT) + 1 - x.lig);   /* the step's row */ \
             ++forkIdx;                                                                             \
             forkT = forkIdx < nEff ? forkT + m : 0x7fffffff;                                       \
         }                                                                                          \
