@@ -85,6 +85,12 @@ struct PassCtx {
     int* bj;                 // LDS: staircase fork rows, this lane's first slot one backward row before its b0 row
 };
 
+// Row word of a row symbol that was staged PRE-MULTIPLIED by 8 (its byte offset in the row-word table): one add for the
+// address instead of a mask and a shift-add per step.
+__device__ __forceinline__ uint2 row_word8(const uint2* tbl, unsigned sym8) {
+    return *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(tbl) + sym8);
+}
+
 // One DP row in G-space over the lane's 4*NQ columns: dst = max3(up, left, diag + w).  FWD walks
 // the columns left to right, the backward pass right to left; src/dst alternate (no register copies).
 template <int NQ, bool FWD>
@@ -137,13 +143,14 @@ __device__ __forceinline__ int bwd_pass(const PassCtx& x, int rowsT, const uint8
     int gk = g * (x.lig - (G - 1));   // g * k' of the row this lane finished before step 0
     int zmax = Ha[0];
     const uint8_t* pa = ct + x.lig;   // row symbol of step t is pa[t]
-    uint2 wordNext = x.tbl[pa[0]];
+    uint2 wordNext = row_word8(x.tbl, pa[0]);
     unsigned symNext = pa[1];
 #define STRK_BSTEP(SRC, DST, T)                                                              \
     {                                                                                        \
         const uint2 word = wordNext;                                                         \
-        wordNext = x.tbl[symNext];                                                           \
+        wordNext = row_word8(x.tbl, symNext);                                                \
         symNext = pa[(T) + 2];                                                               \
+        asm volatile("" : "+v"(symNext));   /* (a plain 32-bit value from here on: no re-masking of the byte next step) */ \
         const int edge = from_right<G>(bstep * ((T) + 1), hout, x.last);                        \
         hout = dp_row<NQ, false>(SRC, DST, sel, word, edge, edgePrev);                       \
         edgePrev = edge;                                                                     \
@@ -200,13 +207,14 @@ __device__ __forceinline__ void fwd_pass(const PassCtx& x, int rowsP, const uint
     int forkIdx = 0;
     const int bjump = STAIR ? (x.first ? kNegInf : *x.bj) : 0;
     const uint8_t* pa = cp + (G - 1) - x.lig;
-    uint2 wordNext = x.tbl[pa[0]];
+    uint2 wordNext = row_word8(x.tbl, pa[0]);
     unsigned symNext = pa[1];
 #define STRK_FSTEP(SRC, DST, T)                                                              \
     {                                                                                        \
         const uint2 word = wordNext;                                                         \
-        wordNext = x.tbl[symNext];                                                           \
+        wordNext = row_word8(x.tbl, symNext);                                                \
         symNext = pa[(T) + 2];                                                               \
+        asm volatile("" : "+v"(symNext));   /* (a plain 32-bit value from here on: no re-masking of the byte next step) */ \
         const int edge = from_left<G>(bstep * ((T) + 1), hout, x.first);                        \
         hout = dp_row<NQ, true>(SRC, DST, sel, word, edge, edgePrev);                        \
         edgePrev = edge;                                                                     \
@@ -260,13 +268,14 @@ __device__ __forceinline__ void fwd_pass_ref(const PassCtx& x, int rowsP, const 
     int forkG = nEff > 0 ? g * fork0 : 0x7fffffff;
     int forkIdx = 0;
     const uint8_t* pa = cp + (G - 1) - x.lig;
-    uint2 wordNext = x.tbl[pa[0]];
+    uint2 wordNext = row_word8(x.tbl, pa[0]);
     unsigned symNext = pa[1];
 #define STRK_RSTEP(SRC, DST, T)                                                              \
     {                                                                                        \
         const uint2 word = wordNext;                                                         \
-        wordNext = x.tbl[symNext];                                                           \
+        wordNext = row_word8(x.tbl, symNext);                                                \
         symNext = pa[(T) + 2];                                                               \
+        asm volatile("" : "+v"(symNext));   /* (a plain 32-bit value from here on: no re-masking of the byte next step) */ \
         const int edge = from_left<G>(bstep * ((T) + 1), hout, x.first);                     \
         hout = dp_row<NQ, true>(SRC, DST, sel, word, edge, edgePrev);                        \
         edgePrev = edge;                                                                     \
@@ -425,7 +434,7 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
             const int row = idx - (G - 1);  // 0-based row
             int sym = kNullSym;
             if (row >= 0 && row < rowsP) sym = row < nfl ? dbs[4 + row] : motifL[ph];
-            cp[idx] = (uint8_t)sym;
+            cp[idx] = (uint8_t)(8 * sym);   // (the byte offset of the symbol's row word: row_word8)
             ph += gstep;
             if (ph >= m) ph -= m;
         }
@@ -435,7 +444,7 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
             int sym = kNullSym;
             if (row >= 0 && row < rowsT) sym = dbs[4 + ndb - 1 - row];
             else if (stair && row >= rowsT && row < rowsT + G - 1) sym = motifL[m - 1 - (row - rowsT) % m];   // the reversed motif, cyclically
-            ct[idx] = (uint8_t)sym;
+            ct[idx] = (uint8_t)(8 * sym);
         }
     }
     wave_lds_sync();
