@@ -368,3 +368,46 @@ def test_contiguous_block_dealing_gives_every_rank_one_balanced_run():
         assert max(sum(cost[k] for k in r) for r in runs) < share + max(cost), world
     # the scatter (counting path) stays what it was: every block exactly once
     assert sorted(k for r in deal_locus_blocks(blocks, 3) for k in r) == list(range(len(blocks)))
+
+
+def test_class_known_band_geometry_equals_the_search_over_the_classes(tmp_path):
+    """band_geometry_of_class (what the band kernels recompute per item from its class) must give exactly what band_geometry
+    (k_plan: the search over the eight classes) gave for every eligible item: same band, same column range.  Host build of
+    strk_search.h, 3 million random shapes incl. long windows and every window half-width."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "geo_check.cpp"
+    src.write_text(r"""
+#include <cstdio>
+#include <random>
+#include <algorithm>
+#include "%s/strkit_amd/csrc/strk_search.h"
+int main() {
+    std::mt19937 rng(7);
+    long n_ok = 0, bad = 0, fly_limits = 0;
+    for (long it = 0; it < 3000000; ++it) {
+        int nfl = 1 + rng() %% 260, nfr = 1 + rng() %% 127, m = 1 + rng() %% ((rng() %% 8 == 0) ? 200 : 24);
+        int est = rng() %% ((rng() %% 4 == 0) ? 2100 : 60);
+        int W = 3 + rng() %% 13;
+        int lo = std::max(0, est - W), n = std::min(32, est + W - lo + 1);
+        int ntr = std::max(0, est * m + (int)(rng() %% 41) - 20);
+        strk::BandGeo a = strk::band_geometry(nfl, ntr, nfr, m, lo, n);
+        if (!a.ok) continue;
+        ++n_ok;
+        if (strk::band_class_fly(a.cls) && (nfl > strk::kBandFlyMaxFlank || m > strk::kBandFlyMaxMotif)) ++fly_limits;
+        strk::BandGeo b = strk::band_geometry_of_class(a.cls, nfl, ntr, m, lo, n);
+        if (a.cls != b.cls || a.G != b.G || a.wd != b.wd || a.dlo != b.dlo || a.bwd != b.bwd || a.bdlo != b.bdlo ||
+            a.cmin != b.cmin || a.ncol != b.ncol) ++bad;
+    }
+    printf("%%ld %%ld %%ld\n", n_ok, bad, fly_limits);
+    return 0;
+}
+""" % root)
+    exe = tmp_path / "geo_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe), str(src)], check=True)
+    n_ok, bad, fly_limits = (int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
+    assert n_ok > 1_000_000 and bad == 0
+    assert fly_limits == 0      # the on-the-fly classes never get a flank or a motif their staged 2 x 256 bytes cannot hold
