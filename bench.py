@@ -136,6 +136,32 @@ def kernel_bytes(acc: dict) -> dict:
             "k_dp_all": acc["exact_bytes"] - acc["long_bytes"], "k_dp_long": acc["long_bytes"], "k_dp_generic": 0}
 
 
+def kernel_cells(acc: dict) -> dict:
+    """DP cells by the kernel that executed them (strk_stats.band_cells ...; the generic kernel's are the remainder)."""
+    named = acc["band_cells"] + acc["wide_cells"] + acc["exact_cells"] + acc["long_cells"]
+    return {"k_dp_band": acc["band_cells"], "k_dp_band_wide": acc["wide_cells"], "k_dp_all": acc["exact_cells"],
+            "k_dp_long": acc["long_cells"], "k_dp_generic": max(0, acc["cells"] - named)}
+
+
+def valu_block(kname: str, cfg: int, k_ms: float, cells_launch: float) -> dict | None:
+    """VALU-issue figures of ONE kernel: instruction count from the committed PMC pass of this command on config `cfg`, this
+    run's un-overlapped duration and this run's cells OF THAT KERNEL."""
+    pmc = pmc_summary(kname, cfg)
+    if not pmc or "SQ_INSTS_VALU" not in pmc:
+        return None
+    clock_ghz = pmc.get("clock_ghz", 2.3)
+    floor_ms = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / N_SIMD / (clock_ghz * 1e9) * 1e3
+    return {"valu_from_profile": f"profiles/{PROFILE_TAG}{'' if cfg == 2 else f'_cfg{cfg}'}_pmc_summary.json",
+            "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES_PER_INST,
+            "valu_clock_ghz": clock_ghz, "floor_ms": floor_ms,
+            "profile_kernel_ms": pmc.get("unoverlapped_avg_us", 0.0) / 1e3,
+            "frac_valu": floor_ms / k_ms, "cells_per_launch": cells_launch,
+            "insts_per_cell": pmc["SQ_INSTS_VALU"] * 64.0 / max(cells_launch, 1.0),
+            "insts_per_cell_floor": DP_INSTS_PER_CELL_FLOOR,
+            "frac_of_cell_floor": (cells_launch / 64.0 * DP_INSTS_PER_CELL_FLOOR * VALU_CYCLES_PER_INST / N_SIMD
+                                   / (clock_ghz * 1e9) * 1e3) / k_ms}
+
+
 def roofline_block(cfg: int, acc_timed: dict, iso: dict | None, n_timed: int, plain: bool) -> dict:
     """`roofline` of the dominant kernel.  iso = per-kernel durations of one call at a time (un-overlapped), or None;
     acc_timed = the same sums over the timed region, where calls_in_flight launches share the device."""
@@ -155,24 +181,30 @@ def roofline_block(cfg: int, acc_timed: dict, iso: dict | None, n_timed: int, pl
                     "kernel_ms_overlapped is the same kernel's event duration inside the timed region, where calls_in_flight "
                     "launches share the CUs (not a throughput denominator)"}
     pmc = pmc_summary(kname, cfg) if plain else None
+    cells_k = iso["cells_k"] if iso else {k: v / n for k, v in kernel_cells(acc_timed).items()}
+    roof["dp_kernels_cells"] = cells_k
     if pmc:
-        roof["traffic"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-        if "SQ_INSTS_VALU" in pmc:
-            clock_ghz = pmc.get("clock_ghz", 2.3)
-            floor_ms = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / N_SIMD / (clock_ghz * 1e9) * 1e3
-            cells_launch = (iso["cells"] if iso else acc_timed["cells"] / n)
-            roof.update({"valu_from_profile": f"profiles/{PROFILE_TAG}{'' if cfg == 2 else f'_cfg{cfg}'}_pmc_summary.json",
-                         "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES_PER_INST,
-                         "valu_clock_ghz": clock_ghz, "floor_ms": floor_ms,
-                         "profile_kernel_ms": pmc.get("unoverlapped_avg_us", 0.0) / 1e3,
-                         "frac_valu": floor_ms / k_ms,
-                         "insts_per_cell": pmc["SQ_INSTS_VALU"] * 64.0 / max(cells_launch, 1.0),
-                         "insts_per_cell_floor": DP_INSTS_PER_CELL_FLOOR,
-                         "frac_of_cell_floor": (cells_launch / 64.0 * DP_INSTS_PER_CELL_FLOOR * VALU_CYCLES_PER_INST / N_SIMD
-                                                / (clock_ghz * 1e9) * 1e3) / k_ms,
-                         "valu_note": "instruction counts come from the committed rocprofv3 PMC pass of this command (a live run cannot "
-                                      "count instructions); cells and kernel_ms are this run's: profile_kernel_ms far from kernel_ms "
-                                      "means the profile is stale"})
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            roof["traffic"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        vb = valu_block(kname, cfg, k_ms, cells_k[kname])
+        if vb:
+            roof.update(vb)
+            roof["valu_note"] = ("instruction counts come from the committed rocprofv3 PMC pass of this command (a live run cannot "
+                                 "count instructions); cells (of THIS kernel) and kernel_ms are this run's: profile_kernel_ms far "
+                                 "from kernel_ms means the profile is stale")
+        # every other DP kernel that takes more than a fifth of the configuration's DP time gets the same figures
+        dp_total = sum(src.values())
+        others = {}
+        for k, _f in DP_KERNELS:
+            if k != kname and src[k] > 0.2 * dp_total:
+                ob = valu_block(k, cfg, max(src[k], 1e-9), cells_k[k])
+                if ob:
+                    pk = pmc_summary(k, cfg)
+                    ob["kernel_ms"] = src[k]
+                    ob["traffic"] = ((2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024.0) if "FETCH_SIZE" in pk and "WRITE_SIZE" in pk else None
+                    others["strk::" + k] = ob
+        if others:
+            roof["other_dp_kernels"] = others
     return roof
 
 
@@ -231,6 +263,12 @@ def run_e2e(data: dict) -> dict:
     return out
 
 
+def bucket_windows(acc: dict) -> dict:
+    """candidate-window half-widths the timed calls ran with, per motif-length bucket that had loci (strk_stats.window_bucket)"""
+    names = ("1-2", "3-4", "5-6", "7-10", "11+")
+    return {names[k]: sorted(v) for k, v in enumerate(acc["window_bucket"]) if v}
+
+
 def progress(msg: str) -> None:
     """Stage marker on stderr (stdout carries the one JSON line only)."""
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -258,6 +296,7 @@ def main() -> None:
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (self-test)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end sub-result (BAM + FASTA + BED -> per-read copy numbers)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` sub-results (BASELINE configs 3, 4-shard, 5 timed on this GPU)")
+    ap.add_argument("--prime", type=int, default=0, help="untimed set-up calls before the warm-up (0: enough for the adaptive state to settle)")
     ap.add_argument("--e2e-loci", type=int, default=10000)
     ap.add_argument("--e2e-depth", type=int, default=30)
     ap.add_argument("--e2e-read-len", type=int, default=15000)
@@ -376,7 +415,8 @@ def main() -> None:
     def new_acc():
         return dict(dp_kernel_ms=0.0, band_kernel_ms=0.0, band_wide_kernel_ms=0.0, long_kernel_ms=0.0, generic_kernel_ms=0.0,
                     head_ms=0.0, replay_ms=0.0, all_ms=0.0, misses=0, fallback=0, dedup=0, band=0, band_fb=0, n=0, reads=0, loci=0,
-                    band_bytes=0, exact_bytes=0, wide_bytes=0, long_bytes=0, cells=0, windows=set())
+                    band_bytes=0, exact_bytes=0, wide_bytes=0, long_bytes=0, cells=0, band_cells=0, wide_cells=0, exact_cells=0,
+                    long_cells=0, windows=set(), window_bucket=[set() for _ in range(5)])
 
     def add_stats(ac, st_, n_reads, n_loci_):
         for _k, f in DP_KERNELS:
@@ -386,7 +426,12 @@ def main() -> None:
         ac["misses"] += st_.n_miss_reads; ac["fallback"] += st_.n_fallback; ac["dedup"] += st_.n_dedup_reads
         ac["band_bytes"] += st_.band_bytes; ac["exact_bytes"] += st_.exact_bytes
         ac["wide_bytes"] += st_.wide_bytes; ac["long_bytes"] += st_.long_bytes; ac["cells"] += st_.dp_cells
+        for _k in ("band_cells", "wide_cells", "exact_cells", "long_cells"):
+            ac[_k] += getattr(st_, _k)
         ac["windows"].add(int(st_.window_used))
+        for _k in range(5):
+            if st_.window_bucket[_k]:
+                ac["window_bucket"][_k].add(int(st_.window_bucket[_k]))
         ac["n"] += 1; ac["reads"] += n_reads; ac["loci"] += n_loci_
 
     acc = new_acc()
@@ -428,7 +473,9 @@ def main() -> None:
     # One-time set-up, outside the W warm-up steps the caller asked for: the first call of every context allocates its
     # workspace and tries the band on a sample of the reads, and the library settles the default candidate window after
     # eight calls without a miss -- none of which belongs to a steady-state step.
-    prime = max(3 * D, 12)
+    # (the window level of a motif-length bucket drops after eight quiet calls, one level at a time: 8 -> 6 takes 8 calls, the
+    # long-motif buckets' 8 -> 6 -> 5 -> 4 takes 24; band probation ends with the first call)
+    prime = a.prime if a.prime > 0 else (max(3 * D, 12) if a.config in (2, 3) else 28)
     progress("priming + warm-up + timed region")
     run(prime, False)
     flush(prime)
@@ -470,6 +517,7 @@ def main() -> None:
         iso_ = {k: ac[f] / n_calls for k, f in DP_KERNELS}
         iso_["bytes"] = {k: v / n_calls for k, v in kernel_bytes(ac).items()}
         iso_["cells"] = ac["cells"] / n_calls
+        iso_["cells_k"] = {k: v / n_calls for k, v in kernel_cells(ac).items()}
         iso_["head_ms"] = ac["head_ms"] / n_calls; iso_["replay_ms"] = ac["replay_ms"] / n_calls; iso_["device_ms"] = ac["all_ms"] / n_calls
         return ac["reads"] / e1, e1 / n_calls * 1e3, iso_, ac
 
@@ -501,7 +549,7 @@ def main() -> None:
         e2 = time.perf_counter() - t2
         bl_h = batches[(1 + nh) % len(hb)]
         extras["h2d_inclusive"] = {"value": r2 / e2, "unit": "reads/s", "ms_per_step": e2 / nh * 1e3, "steps": nh,
-                                   "sub_batches_per_step": int(st.n_dp_launches),
+                                   "sub_batches_per_step": int(st.n_sub_batches),
                                    "bytes_h2d_per_step": int(bl_h.seqs.nbytes + bl_h.n_reads * 24),
                                    "note": "strk_count_loci with pageable host buffers in and out, one call at a time; inside a call "
                                            "sub-batches of whole loci travel through four pinned slots and two compute contexts (strk_host_pipe.inc); never "
@@ -619,7 +667,10 @@ def main() -> None:
         res_c = [resident(b) for b in bl_c]
         rows_c = max(b.n_reads for b in bl_c)
         out_c = torch.zeros((D + 1, NF, rows_c), dtype=torch.int32, device=dev)
-        n_prime = 12                           # band probation, window level, history-sized grids settle
+        # a new sample: the library forgets the previous configuration's window levels, then primes until its own are quiet
+        # (band probation, history-sized grids; 8 -> 6 takes 8 quiet calls, the long-motif buckets' 8 -> 6 -> 5 -> 4 takes 24)
+        L.strk_adaptive_reset()
+        n_prime = 28 if c in (4, 5) else 12
         for i in range(n_prime):
             _lib.check(L.strk_count_loci_device(ctxs[i % D].handle, C.byref(res_c[i % 2][1]), C.byref(p), out_c[0, 1].data_ptr(),
                                                 out_c[0, 2].data_ptr(), out_c[0, 3].data_ptr(), out_c[0, 4].data_ptr(),
@@ -650,7 +701,7 @@ def main() -> None:
             "workload": SUB_CONFIGS[name][2], "loci_per_step": bl_c[0].n_loci, "reads_per_step": bl_c[0].n_reads,
             "value": ac_c["reads"] / el_c, "unit": "reads/s", "steps": k_steps, "ms_per_step": el_c / k_steps * 1e3, "calls_in_flight": D,
             "one_call_at_a_time": {"value": v1c, "ms_per_step": ms1c},
-            "window": sorted(ac_c["windows"]), "band_reads_per_step": ac_c["band"] / ac_c["n"],
+            "window": sorted(ac_c["windows"]), "window_by_motif_bucket": bucket_windows(ac_c), "band_reads_per_step": ac_c["band"] / ac_c["n"],
             "band_fallback_per_step": ac_c["band_fb"] / ac_c["n"], "window_miss_reads_per_step": ac_c["misses"] / ac_c["n"],
             "generic_kernel_items_per_step": ac_c["fallback"] / ac_c["n"], "dedup_reads_per_step": ac_c["dedup"] / ac_c["n"],
             "gcups": iso_c["cells"] / max(dp_ms_c, 1e-9) / 1e6, "roofline": roof_c,
@@ -678,7 +729,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
             "config": {"workload": wl, "loci_per_step_per_gpu": b0.n_loci, "reads_per_step_per_gpu": b0.n_reads,
-                       "distinct_batches": NB, "window": sorted(acc["windows"]),
+                       "distinct_batches": NB, "window": sorted(acc["windows"]), "window_by_motif_bucket": bucket_windows(acc),
                        "parallelism": f"loci-sharded x{a.gpus}" + (f" + all_gather every {G} steps" if use_dist else ""),
                        "calls_in_flight": D},
             "loci_per_s": loci_all / elapsed,

@@ -137,12 +137,27 @@ typedef struct strk_stats {
     int32_t n_long_reads;      /* reads scored by k_dp_long */
     int64_t wide_bytes;        /* algorithmic bytes of the reads routed to k_dp_band_wide (part of band_bytes) */
     int64_t long_bytes;        /* ... to k_dp_long (part of exact_bytes) */
+    int64_t band_cells;        /* dp_cells by the kernel that executed them: k_dp_band (band classes of 8 and 16 lanes per read), */
+    int64_t wide_cells;        /* ... k_dp_band_wide (32 and 64 lanes), */
+    int64_t exact_cells;       /* ... k_dp_all / k_dp_ref, */
+    int64_t long_cells;        /* ... k_dp_long; the remainder of dp_cells is the generic kernel's */
+    int32_t window_bucket[5];  /* candidate-window half-width per motif-length bucket (1-2, 3-4, 5-6, 7-10, 11+ bases) this call
+                                  ran with; 0: the call held no locus of that bucket */
+    int32_t n_sub_batches;     /* strk_count_loci on host buffers: sub-batches the call was cut into (0: one piece) */
 } strk_stats;
+/* strk_count_loci on large HOST batches runs as a pipeline of sub-batches on two contexts (csrc/strk_host_pipe.inc): the *_ms
+ * fields, *_bytes, *_cells and the n_* counts are then SUMS over the sub-batches — sub-batches overlap, so the sum of their
+ * device times can exceed the call's wall time (it is not a throughput denominator); window_used / window_bucket are the last
+ * sub-batch's.  Device-resident entry points (strk_count_loci_device, strk_submit_loci_device + strk_finish) report one call. */
 
 int strk_init(int device, strk_ctx** out);
 void strk_destroy(strk_ctx* ctx);
 const char* strk_last_error(void);
 const char* strk_version(void);
+/* Forget what the library has learnt about the current sample (the default candidate-window level per motif-length bucket,
+ * process-wide): call it when a process moves on to ANOTHER sample (the reference runs one sample per process,
+ * call_sample.py:265).  Per-context state (band probation, grid history) goes with strk_destroy. */
+void strk_adaptive_reset(void);
 /* free / total memory of a device in bytes (hipMemGetInfo): how the file front end decides whether an alignment file's
  * decompressed form stays resident or is streamed in spans. */
 int strk_device_mem(int device, int64_t* free_bytes, int64_t* total_bytes);

@@ -42,14 +42,16 @@ class StrkStats(C.Structure):
                 ("n_band_fallback", C.c_int32), ("band_kernel_ms", C.c_float), ("window_used", C.c_int32),
                 ("band_bytes", C.c_int64), ("exact_bytes", C.c_int64), ("band_wide_kernel_ms", C.c_float),
                 ("long_kernel_ms", C.c_float), ("generic_kernel_ms", C.c_float), ("head_ms", C.c_float), ("replay_ms", C.c_float),
-                ("n_long_reads", C.c_int32), ("wide_bytes", C.c_int64), ("long_bytes", C.c_int64)]
+                ("n_long_reads", C.c_int32), ("wide_bytes", C.c_int64), ("long_bytes", C.c_int64),
+                ("band_cells", C.c_int64), ("wide_cells", C.c_int64), ("exact_cells", C.c_int64), ("long_cells", C.c_int64),
+                ("window_bucket", C.c_int32 * 5), ("n_sub_batches", C.c_int32)]
 
     def as_dict(self) -> dict:
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k == "window_bucket" else getattr(self, k)) for k, _ in self._fields_}
 
 
 # Every symbol include/strkit_amd.h declares (tests check the .so exports exactly these).
-EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_device_mem", "strk_host_register", "strk_host_unregister",
+EXPORTS = ("strk_init", "strk_destroy", "strk_last_error", "strk_version", "strk_adaptive_reset", "strk_device_mem", "strk_host_register", "strk_host_unregister",
            "strk_host_is_pinned", "strk_repeat_count", "strk_count_loci",
            "strk_count_loci_device", "strk_submit_loci_device", "strk_finish", "strk_score_table",
            "strk_score_ref_table", "strk_ref_repeat_count", "strk_ref_repeat_count_batch", "strk_realign", "strk_realign_i16_flags", "strk_bam_scan",
@@ -96,6 +98,8 @@ def load(build: bool = True):
         L.strk_destroy.argtypes = [C.c_void_p]
         L.strk_last_error.restype = C.c_char_p
         L.strk_version.restype = C.c_char_p
+        L.strk_adaptive_reset.restype = None
+        L.strk_adaptive_reset.argtypes = []
         L.strk_repeat_count.restype = C.c_int
         L.strk_repeat_count.argtypes = ([C.c_void_p, C.c_int32] + [C.c_char_p, C.c_int32] * 4 + [C.c_int32] * 3
                                         + [_i32p] * 3)

@@ -45,7 +45,7 @@ extern "C" int strk_repeat_count(strk_ctx* ctx, int32_t start_count, const uint8
 namespace {
 
 thread_local std::string g_err;
-constexpr int kWinStartLevel = 1, kWinLevels = 4;   // kWindowLevels below: a process starts at 8 sizes either side of the estimate
+constexpr int kWinStartLevel = 3, kWinLevels = 6;   // kWindowLevels below: a process starts at 8 sizes either side of the estimate
 struct HostPipe;   // strk_host_pipe.inc: the pinned-slot pipeline behind strk_count_loci
 
 // batched calls submitted and not yet finished, over all contexts of this process: a call that will share the
@@ -58,9 +58,10 @@ std::atomic<int> g_calls_in_flight{0};
 // once; eight (from the two widest levels: sixty-four) calls in a row with at most one miss per two thousand loci move
 // a level down.
 // One level per motif-length bucket (win_bucket): the estimate round(|tr| / |motif|) is off by the read's indel drift divided
-// by the motif length, so the reads of long motifs stay inside narrow windows that those of short ones leave.
-std::atomic<int> g_win_level[4] = {{kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}};
-std::atomic<int> g_win_quiet[4] = {{0}, {0}, {0}, {0}};
+// by the motif length, so the reads of long motifs stay inside narrow windows that those of short ones leave.  The two
+// narrowest levels (+-4, +-5) are open to the long-motif buckets only (kWinMinLevel).
+std::atomic<int> g_win_level[strk::kWinBuckets] = {{kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}};
+std::atomic<int> g_win_quiet[strk::kWinBuckets] = {{0}, {0}, {0}, {0}, {0}};
 
 // CPUs this process may run on (a container's share, not the machine's core count)
 int host_cpus() {
@@ -101,6 +102,7 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;
+            (void)hipGetLastError();   // the failed hipMalloc's error is sticky per thread: a retry with less memory must not meet it
             return fail(STRK_E_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
         }
         cap = want;
@@ -136,7 +138,7 @@ struct strk_ctx {
     int band_penalty = 32;   // length of the next cool-down (doubles while retries keep failing)
     bool band_probation = true;   // the band has not proved itself on this context's data yet: only a sample of the reads takes it
     bool p_window_auto = false;
-    int p_window_b[4] = {0, 0, 0, 0};   // the pending call's window per motif-length bucket (0: params.window for all)
+    int p_window_b[strk::kWinBuckets] = {0, 0, 0, 0, 0};   // the pending call's window per motif-length bucket (0: params.window for all)
     // work-queue lengths of the previous finished call (wave chunks), used to size the persistent grids of the
     // kernels that usually have little or nothing to do: an idle block still claims its 70-80 KB of LDS on a CU
     // and so delays the band blocks of the calls it overlaps with
@@ -159,10 +161,13 @@ using namespace strk;
 constexpr int kDefaultWindow = 8;
 enum { kEvStart = 0, kEvHead, kEvBand, kEvWide, kEvPre, kEvExact, kEvLong, kEvGeneric, kEvEnd, kNumEvents };
 constexpr int kBandProbationReads = 2048;
-// default half-widths of the candidate window, see g_win_level.  (5 was tried as the narrowest level: the search from a start
-// the feedback moved by one size then ends at the window's edge, 780 reads per 10 000-locus call turn out uncertain and one or
-// two leave the window: 205 M reads/s instead of 221 M.)
-constexpr int kWindowLevels[kWinLevels] = {6, 8, 11, 15};
+// default half-widths of the candidate window, see g_win_level.  A search that converges at once scores start +- 4, so +-4 is
+// the floor; it holds where the estimate round(|tr| / |motif|) is never off by a size, i.e. for long motifs (tools/window_need.py
+// on BASELINE config 4: motifs of 11+ bases never need more, 7-10 bases in 0.7 % of the loci, 5-6 bases in 6 %, 3-4 in 27 %).
+// The short-motif buckets stop at +-6: +-5 was tried there in round 3 (the search from a start the feedback moved by one size
+// then ends at the window's edge, 780 reads per 10 000-locus call turn out uncertain: 205 M reads/s instead of 221 M).
+constexpr int kWindowLevels[kWinLevels] = {4, 5, 6, 8, 11, 15};
+constexpr int kWinMinLevel[kWinBuckets] = {2, 2, 2, 0, 0};   // narrowest level a motif-length bucket may settle at
 // Scratch pool (int32 units): kLongWaves slots of kLongSlotInts for k_dp_long (one per resident wave; a slot
 // holds the backward row of all column tiles + two boundary columns: windows up to ~16 kb), then 16 Mi
 // ints of H rows for the generic kernel.  448 MiB of the 288 GB, allocated once per context.
@@ -172,7 +177,7 @@ constexpr size_t kLongSlotInts = (size_t)48 << 10;
 constexpr size_t kScratchInts = kLongWaves * kLongSlotInts + ((size_t)16 << 20);
 // device layout of the `counters` buffer: int32[kCntTotal] | pad | u64 cells | u64 scratch_used
 constexpr size_t kCellsOff = 64 * sizeof(int32_t);
-constexpr size_t kCountersBytes = kCellsOff + 6 * sizeof(unsigned long long);   // cells, scratch_used, band / exact / wide-band / long-kernel bytes
+constexpr size_t kCountersBytes = kCellsOff + 10 * sizeof(unsigned long long);   // cells, scratch_used, band / exact / wide-band / long-kernel bytes, cells per kernel (kCell*)
 
 int check_params(const strk_params* p, strk_params* out) {
     if (!p) return fail(STRK_E_INVALID, "params is NULL");
@@ -240,7 +245,7 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
     a.dbg = dbg;
     a.end_flags = end_flags;
     a.window = window;
-    for (int k = 0; k < 4; ++k) a.window_b[k] = c->p_window_b[k] > 0 ? c->p_window_b[k] : window;
+    for (int k = 0; k < kWinBuckets; ++k) a.window_b[k] = c->p_window_b[k] > 0 ? c->p_window_b[k] : window;
     a.table_stride = table_stride;
     if (sp) {  // speculative search for start == est_cn inside the DP kernel
         a.spec = static_cast<int4*>(c->spec.p);
@@ -326,12 +331,25 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     if (!b || b->n_reads < 0 || b->n_loci < 0) return fail(STRK_E_INVALID, "bad batch");
     // default window: 8 sizes either side of the estimate to begin with, then what the sample needs (g_win_level)
     c->p_window_auto = params->window <= 0;
-    for (int k = 0; k < 4; ++k) c->p_window_b[k] = 0;
+    for (int k = 0; k < kWinBuckets; ++k) c->p_window_b[k] = 0;
     if (c->p_window_auto) {
+        // tuning aid: STRKIT_AMD_WINDOW_B="w0,w1,w2,w3,w4" pins the default window of each motif-length bucket (0: adaptive)
+        static const std::array<int, kWinBuckets> pinned = [] {
+            std::array<int, kWinBuckets> v{};
+            if (const char* e = getenv("STRKIT_AMD_WINDOW_B")) {
+                for (int k = 0; k < kWinBuckets && *e; ++k) {
+                    v[k] = atoi(e);
+                    while (*e && *e != ',') ++e;
+                    if (*e == ',') ++e;
+                }
+            }
+            return v;
+        }();
         p.window = 0;
-        for (int k = 0; k < 4; ++k) {
-            const int w = kWindowLevels[std::min(kWinLevels - 1, std::max(0, g_win_level[k].load(std::memory_order_relaxed)))];
-            c->p_window_b[k] = std::max(w, std::min(kWindowLevels[kWinLevels - 1], p.local_search_range + p.step_size + 2));
+        for (int k = 0; k < kWinBuckets; ++k) {
+            const int w = pinned[k] > 0 ? std::min(pinned[k], kWindowLevels[kWinLevels - 1])
+                                        : kWindowLevels[std::min(kWinLevels - 1, std::max(kWinMinLevel[k], g_win_level[k].load(std::memory_order_relaxed)))];
+            c->p_window_b[k] = std::max(w, std::min(kWindowLevels[kWinLevels - 1], p.local_search_range + p.step_size));
             p.window = std::max(p.window, c->p_window_b[k]);
         }
     }
@@ -413,14 +431,19 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
             stats->exact_bytes = (int64_t)u[3];
             stats->wide_bytes = (int64_t)u[4];
             stats->long_bytes = (int64_t)u[5];
+            stats->band_cells = (int64_t)u[kCellBand];
+            stats->wide_cells = (int64_t)u[kCellWide];
+            stats->exact_cells = (int64_t)u[kCellExact];
+            stats->long_cells = (int64_t)u[kCellLong];
         }
         stats->n_long_reads = c->h_counters[kCntClass0 + kLongClass];
         stats->n_dp_launches = 2;
         stats->window_used = c->p_params.window;
+        for (int k = 0; k < kWinBuckets; ++k)   // the window each motif-length bucket ran with (0: no locus of that bucket in the call)
+            stats->window_bucket[k] = c->h_counters[kCntLociB + k] > 0 ? (c->p_window_b[k] > 0 ? c->p_window_b[k] : c->p_params.window) : 0;
         if (c->p_window_auto) {   // the widest default window among the motif-length buckets that had loci in this call
             int w = 0;
-            for (int k = 0; k < 4; ++k)
-                if (c->h_counters[kCntLociB + k] > 0) w = std::max(w, c->p_window_b[k]);
+            for (int k = 0; k < kWinBuckets; ++k) w = std::max(w, stats->window_bucket[k]);
             if (w > 0) stats->window_used = w;
         }
         stats->n_fallback = c->h_counters[kCntClass0 + kGenericClass];
@@ -431,26 +454,26 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         stats->dp_cells = (int64_t) * reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
     }
 #ifdef STRK_PHASE_TIMING
-    fprintf(stderr, "[phase ticks/64] header %d stage %d (of which pads %d, window bytes %d) tables %d bwd %d fwd %d epilogue %d\n", c->h_counters[40],
-            c->h_counters[41] + c->h_counters[46] + c->h_counters[47], c->h_counters[47], c->h_counters[46], c->h_counters[42], c->h_counters[43],
-            c->h_counters[44], c->h_counters[45]);
+    fprintf(stderr, "[phase ticks/64] header %d stage %d (of which pads %d, window bytes %d) tables %d bwd %d fwd %d epilogue %d\n", c->h_counters[48],
+            c->h_counters[49] + c->h_counters[54] + c->h_counters[55], c->h_counters[55], c->h_counters[54], c->h_counters[50], c->h_counters[51],
+            c->h_counters[52], c->h_counters[53]);
 #endif
     int n_band_reads = 0;
     for (int k = 0; k < kNumBandClasses; ++k) n_band_reads += c->h_counters[kCntClass0 + kBandClass0 + k];
     // (a call whose band certificates mostly failed reports those reads as misses too: not a window problem)
     const bool band_unhealthy = c->p_args.band_mode && n_band_reads >= 64 && 2 * c->h_counters[kCntBandFallback] > n_band_reads;
     if (c->p_window_auto && !band_unhealthy) {
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kWinBuckets; ++k) {
             const int n_loci_k = c->h_counters[kCntLociB + k], n_miss = c->h_counters[kCntMissB + k];
             if (n_loci_k == 0) continue;
-            const int level = g_win_level[k].load(std::memory_order_relaxed);
+            const int level = std::max(kWinMinLevel[k], g_win_level[k].load(std::memory_order_relaxed));
             // a handful of misses costs less (one short extra round) than a wider window for every read does
             if (n_miss > std::max(2, n_loci_k / 250)) {
                 if (level < kWinLevels - 1) g_win_level[k].store(level + 1, std::memory_order_relaxed);
-                g_win_quiet[k].store(level == 0 ? -56 : 0, std::memory_order_relaxed);   // a failed narrow window is not retried soon
+                g_win_quiet[k].store(level < kWinStartLevel ? -56 : 0, std::memory_order_relaxed);   // a failed narrow window is not retried soon
             } else if (n_miss > std::max(1, n_loci_k / 1000)) {   // more than one locus in a thousand: not a quiet call
                 g_win_quiet[k].store(0, std::memory_order_relaxed);
-            } else if (g_win_quiet[k].fetch_add(1, std::memory_order_relaxed) + 1 >= (level >= 2 ? 64 : 8) && level > 0) {
+            } else if (g_win_quiet[k].fetch_add(1, std::memory_order_relaxed) + 1 >= (level > kWinStartLevel ? 64 : 8) && level > kWinMinLevel[k]) {
                 g_win_level[k].store(level - 1, std::memory_order_relaxed);
                 g_win_quiet[k].store(0, std::memory_order_relaxed);
             }
@@ -642,6 +665,13 @@ extern "C" {
 const char* strk_last_error(void) { return g_err.c_str(); }
 const char* strk_version(void) { return "strkit_amd 0.1.0 (gfx950)"; }
 
+void strk_adaptive_reset(void) {
+    for (int k = 0; k < strk::kWinBuckets; ++k) {
+        g_win_level[k].store(kWinStartLevel, std::memory_order_relaxed);
+        g_win_quiet[k].store(0, std::memory_order_relaxed);
+    }
+}
+
 int strk_host_register(void* ptr, int64_t bytes) {
     if (!ptr || bytes <= 0) return fail(STRK_E_INVALID, "strk_host_register: null pointer or no bytes");
     const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
@@ -753,7 +783,7 @@ int strk_count_loci_dseqs(strk_ctx* ctx, const strk_batch* batch, const void* d_
             return fail(STRK_E_INVALID, "d_seqs is not device memory of device %d (the context's)", ctx->device);
         }
     }
-    if (!d_seqs) {   // host bases: large batches go through the pinned three-slot pipeline (strk_host_pipe.inc)
+    if (!d_seqs) {   // host bases: large batches go through the pinned four-slot pipeline (strk_host_pipe.inc)
         bool taken = false;
         rc = count_loci_pipelined(ctx, batch, params, out_cn, out_score, out_n_iters, out_start, stats, &taken);
         if (taken) return rc;

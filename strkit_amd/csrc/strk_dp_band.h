@@ -282,12 +282,12 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
 }
 
 // Profiling aid (tools/phase_timing.sh builds a private copy of the library with -DSTRK_PHASE_TIMING): shader-clock
-// ticks per phase of band_wave, summed over waves into the spare counter slots 40..47.
+// ticks per phase of band_wave, summed over waves into the spare counter slots 48..55.
 #ifdef STRK_PHASE_TIMING
 #define STRK_PHASE(i)                                                                                  \
     do {                                                                                               \
         const unsigned long long t_ = __builtin_readcyclecounter();                                    \
-        if (lane == 0) atomicAdd(&a.counters[40 + (i)], (int)((t_ - tphase) >> 6));                    \
+        if (lane == 0) atomicAdd(&a.counters[48 + (i)], (int)((t_ - tphase) >> 6));                    \
         tphase = t_;                                                                                   \
     } while (0)
 #else
@@ -513,8 +513,11 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
             }
             a.exact[r] = 1;
             atomicAdd(&a.counters[kCntBandFallback], 1);
-            if (c != kGenericClass)
-                atomicAdd(a.cells, (unsigned long long)ndb * ((unsigned long long)nfl + (unsigned long long)(lo + n - 1) * m + nfr));
+            if (c != kGenericClass) {
+                const unsigned long long cc = (unsigned long long)ndb * ((unsigned long long)nfl + (unsigned long long)(lo + n - 1) * m + nfr);
+                atomicAdd(a.cells, cc);
+                atomicAdd(a.cells + cell_slot_of_list(c), cc);
+            }
         }
     }
     wave_lds_sync();

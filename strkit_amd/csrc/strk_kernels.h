@@ -82,7 +82,8 @@ struct KArgs {
     int32_t* counters;    // see Counter enum
     unsigned long long* cells;  // DP cells executed; cells[2] / cells[3]: algorithmic bytes (|window| + 16 per read) of the
                                 // items routed to the band kernels / to the exact kernels by k_plan; cells[4] / cells[5]: the part
-                                // of those that k_dp_band_wide / k_dp_long take
+                                // of those that k_dp_band_wide / k_dp_long take; cells[6..9]: the cells of cells[0] by the kernel
+                                // that executes them: k_dp_band, k_dp_band_wide, k_dp_all / k_dp_ref, k_dp_long (kCell*)
     int32_t* scratch;     // generic kernel rows
     long long scratch_cap;      // in int32 units; [0, long_waves * long_slot) belongs to k_dp_long (one slot
                                 //   per resident wave), the rest is handed out by the generic kernel's bump allocator
@@ -95,7 +96,7 @@ struct KArgs {
     int32_t list_stride;
     int32_t end_flags;
     int32_t window;       // half width (plan kernel): the largest of window_b
-    int32_t window_b[4];  // ... per motif-length bucket (win_bucket): the estimate round(|tr| / |motif|) is off by the read's
+    int32_t window_b[5];  // ... per motif-length bucket (win_bucket): the estimate round(|tr| / |motif|) is off by the read's
                           //    indel drift DIVIDED by the motif length, so long motifs get by with narrow windows
     int32_t table_stride; // entries per read (plan kernel)
     int32_t max_iters, lsr, step, tie_last;  // search parameters (speculative search in k_dp_all)
@@ -117,12 +118,22 @@ enum Counter {
     kCntNextLong = kNumLists + 4,         // work queue head of k_dp_long
     kCntNextBand = kNumLists + 5,         // work queue heads of k_dp_band (+0) and k_dp_band_wide (+1)
     kCntBandFallback = kNumLists + 7,     // band reads whose search could not be certified (re-scored exactly)
-    kCntMissB = kNumLists + 8,            // [4] loci whose search left the table window, per motif-length bucket
-    kCntLociB = kNumLists + 12,           // [4] loci per motif-length bucket
-    kCntTotal = kNumLists + 16
+    kCntMissB = kNumLists + 8,            // [kWinBuckets] loci whose search left the table window, per motif-length bucket
+    kCntLociB = kNumLists + 8 + 5,        // [kWinBuckets] loci per motif-length bucket
+    kCntTotal = kNumLists + 8 + 10
 };
-// motif-length buckets of the adaptive candidate window: 1-2, 3-4, 5-8, 9 and more bases
-__host__ __device__ constexpr int win_bucket(int m) { return m <= 2 ? 0 : (m <= 4 ? 1 : (m <= 8 ? 2 : 3)); }
+// motif-length buckets of the adaptive candidate window: 1-2, 3-4, 5-6, 7-10, 11 and more bases (round 4: the two long-motif
+// buckets may go below +-6 — tools/window_need.py: no locus of BASELINE config 4 with a motif of 11+ bases needs more than
+// +-4, 0.7 % of those with 7-10 bases do — and a narrow window is what puts a long motif's band into 256 instead of 384 diagonals)
+constexpr int kWinBuckets = 5;
+__host__ __device__ constexpr int win_bucket(int m) { return m <= 2 ? 0 : (m <= 4 ? 1 : (m <= 6 ? 2 : (m <= 10 ? 3 : 4))); }
+static_assert(kCntTotal <= 48, "counters 48..55 belong to the phase-timing aid, the 64-bit counters start at int 64");
+// slots of KArgs::cells that split cells[0] by kernel; cell_slot_of_list: the slot of a class list's kernel (-1: generic)
+constexpr int kCellBand = 6, kCellWide = 7, kCellExact = 8, kCellLong = 9;
+__host__ __device__ constexpr int cell_slot_of_list(int c) {
+    return c >= kBandClass0 ? (band_class_wide_kernel(c - kBandClass0) ? kCellWide : kCellBand)
+                            : (c == kLongClass ? kCellLong : (c == kGenericClass ? -1 : kCellExact));
+}
 constexpr int kErrBadInput = 1;   // empty motif / negative length
 constexpr int kErrScratch = 2;    // generic scratch exhausted
 constexpr int kErrEmpty = 4;      // nothing scored for some read
@@ -213,13 +224,14 @@ __device__ inline bool same_read(const KArgs& a, int r, int q) {
 __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* items, int n_items, int force_generic) {
     __shared__ int s_cnt[kNumLists];
     __shared__ int s_base[kNumLists];
-    __shared__ unsigned long long s_cells, s_bytes_band, s_bytes_exact, s_bytes_wide, s_bytes_long;
+    __shared__ unsigned long long s_cells, s_bytes_band, s_bytes_exact, s_bytes_wide, s_bytes_long, s_cells_k[4];
     __shared__ __attribute__((aligned(16))) unsigned s_key[256];
     __shared__ int s_below[kNumBandClasses];   // band items of this block in band classes below c
-    __shared__ int s_lb[4];   // loci per motif-length bucket (counted at a locus's first read)
-    if (threadIdx.x < 4) s_lb[threadIdx.x] = 0;
+    __shared__ int s_lb[kWinBuckets];   // loci per motif-length bucket (counted at a locus's first read)
+    if (threadIdx.x < kWinBuckets) s_lb[threadIdx.x] = 0;
     if (threadIdx.x < kNumLists) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_cells = 0; s_bytes_band = 0; s_bytes_exact = 0; s_bytes_wide = 0; s_bytes_long = 0; }
+    if (threadIdx.x < 4) s_cells_k[threadIdx.x] = 0;
     __syncthreads();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int r = 0, l = 0, nfl = 0, ntr = 0, nfr = 0, m = 1, lo = 0, n = 0;
@@ -288,13 +300,16 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
         const int c = band_list >= 0 ? band_list : classify(nfl, ntr, nfr, m, lo + k0, nn, force_generic, a.ref_mode);
         if (k0 == 0) first_c = c;
         atomicAdd(&s_cnt[c], 1);
+        unsigned long long cc = 0;
         if (c == kGenericClass) {
-            for (int k = 0; k < nn; ++k) cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + k) * m + nfr);
+            for (int k = 0; k < nn; ++k) cc += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + k) * m + nfr);
         } else if (band_list >= 0) {
-            cells += (unsigned long long)band_class_wd(band_list - kBandClass0) * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
+            cc = (unsigned long long)band_class_wd(band_list - kBandClass0) * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
         } else {
-            cells += ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
+            cc = ndb * ((unsigned long long)nfl + (unsigned long long)(lo + k0 + nn - 1) * m + nfr);
         }
+        cells += cc;
+        if (cc && cell_slot_of_list(c) >= 0) atomicAdd(&s_cells_k[cell_slot_of_list(c) - kCellBand], cc);
     }
     if (cells) {
         atomicAdd(&s_cells, cells);
@@ -315,13 +330,15 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     }
     __syncthreads();
     if (threadIdx.x < kNumLists) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x < 4 && s_lb[threadIdx.x]) atomicAdd(&a.counters[kCntLociB + threadIdx.x], s_lb[threadIdx.x]);
+    if (threadIdx.x < kWinBuckets && s_lb[threadIdx.x]) atomicAdd(&a.counters[kCntLociB + threadIdx.x], s_lb[threadIdx.x]);
     if (threadIdx.x == 0 && s_cells) {
         atomicAdd(a.cells, s_cells);
         if (s_bytes_band) atomicAdd(a.cells + 2, s_bytes_band);
         if (s_bytes_exact) atomicAdd(a.cells + 3, s_bytes_exact);
         if (s_bytes_wide) atomicAdd(a.cells + 4, s_bytes_wide);
         if (s_bytes_long) atomicAdd(a.cells + 5, s_bytes_long);
+        for (int k = 0; k < 4; ++k)
+            if (s_cells_k[k]) atomicAdd(a.cells + kCellBand + k, s_cells_k[k]);
     }
     __syncthreads();
     // Band items of a block are listed in the order of (band class, prefix rows): the band kernel runs the 8 (4, 2, 1) items of

@@ -118,9 +118,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRK_RE
                                 atomicOr(&a.counters[kCntError], kErrScratch);
                             }
                             atomicAdd(&a.counters[kCntBandFallback], 1);
-                            if (cls != kGenericClass)
-                                atomicAdd(a.cells, (unsigned long long)(a.nfl[rq] + a.ntr[rq] + a.nfr[rq]) *
-                                                       ((unsigned long long)a.nfl[rq] + (unsigned long long)(a.win_lo[rq] + a.win_n[rq] - 1) * m + a.nfr[rq]));
+                            if (cls != kGenericClass) {
+                                const unsigned long long cc = (unsigned long long)(a.nfl[rq] + a.ntr[rq] + a.nfr[rq]) *
+                                                              ((unsigned long long)a.nfl[rq] + (unsigned long long)(a.win_lo[rq] + a.win_n[rq] - 1) * m + a.nfr[rq]);
+                                atomicAdd(a.cells, cc);
+                                atomicAdd(a.cells + cell_slot_of_list(cls), cc);
+                            }
                         }
                         rescore = true;
                         break;

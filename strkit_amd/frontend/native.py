@@ -244,9 +244,14 @@ class IndexedBam:
 
     @staticmethod
     def _read_bai(path: str, n_contigs: int, bam_path: str | None = None) -> list[np.ndarray]:
-        # an index older than its alignment file describes another file's record chain (as for the .fai, fasta.py)
+        # An index older than its alignment file MAY describe another file's record chain, but a plain `cp`, an rsync without
+        # -t or a download in the other order look the same: warn, as htslib does, and go on.  A stale or foreign index is
+        # caught where it matters: a record chain that does not end on the next entry point (k_dbam_scan's chain-end status,
+        # the host scan's bounds checks).
         if bam_path is not None and os.path.getmtime(path) + 1.0 < os.path.getmtime(bam_path):
-            raise ValueError(f"{path} is older than {bam_path}: re-index the alignment file")
+            import warnings
+            warnings.warn(f"{path} is older than {bam_path}: the index may be stale (re-index the alignment file if records go missing)",
+                          RuntimeWarning, stacklevel=3)
         raw = np.fromfile(path, np.uint8)
         if raw[:4].tobytes() != b"BAI\x01":
             raise ValueError(f"{path}: not a BAI index")

@@ -580,6 +580,13 @@ def test_indexed_bam_slots_reuse_their_buffers(tmp_path):
         if k >= 2:
             assert np.shares_memory(reg.data, ib._pool[k % 2])
     assert set(ib._pool) == {0, 1}
+    # an index that is OLDER than its file (plain cp, rsync without -t) only warns, as htslib does: the same records come back
+    bai = t["paths"]["bam"] + ".bai"
+    old = os.path.getmtime(t["paths"]["bam"]) - 3600
+    os.utime(bai, (old, old))
+    with pytest.warns(RuntimeWarning, match="older than"):
+        ib2 = IndexedBam(t["paths"]["bam"])
+    assert ib2.region("chr1", 0, 150000).n_records == plain[0].n_records
 
 
 def test_fasta_loader_handles_line_shapes(tmp_path):

@@ -206,12 +206,13 @@ def test_host_buffer_entry_point_is_pipelined_and_equal(monkeypatch):
     try:
         got, st = _run(b, ctx)
         _compare(b, got, exp)
-        assert st["n_dp_launches"] >= 6, st                   # sub-batches
+        assert st["n_sub_batches"] >= 6 and st["n_dp_launches"] >= 2 * st["n_sub_batches"], st   # launch rounds add up over the sub-batches
         assert st["n_band_reads"] + st["n_dedup_reads"] > b.n_reads // 2 and st["kernel_ms"] > 0
         monkeypatch.setenv("STRKIT_AMD_PIPE_MB", "4096")     # too small to cut up: the direct path
         got1, st1 = _run(b, ctx)
         _compare(b, got1, exp)
-        assert st1["n_dp_launches"] == 2
+        assert st1["n_dp_launches"] == 2 and st1["n_sub_batches"] == 0
+        assert st1["band_cells"] + st1["wide_cells"] + st1["exact_cells"] + st1["long_cells"] <= st1["dp_cells"] and st1["band_cells"] > 0
     finally:
         ctx.close()
 
@@ -283,7 +284,7 @@ def test_host_entry_point_reads_page_locked_arrays_in_place(gpu_ctx):
         outs = [np.zeros(b.n_reads, np.int32) for _ in range(4)]
         st = _lib.StrkStats()
         _lib.check(L.strk_count_loci(gpu_ctx.handle, C.byref(s), C.byref(p), *[o.ctypes.data for o in outs], C.byref(st)))
-        return outs, int(st.n_dp_launches), keep
+        return outs, int(st.n_sub_batches), keep
 
     plain, n_sub, _ = run()
     assert n_sub > 1

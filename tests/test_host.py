@@ -67,7 +67,7 @@ def test_init_fails_loudly_without_a_gpu_and_errors_are_reported():
 
 def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.StrkParams) == 40
-    assert C.sizeof(_lib.StrkStats) == 112
+    assert C.sizeof(_lib.StrkStats) == 168
     assert C.sizeof(_lib.StrkBatch) == 8 + 9 * 8
 
 
