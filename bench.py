@@ -40,12 +40,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 N_SIMD = 256 * 4
-# Measured on MI355X (profiles/r02_valu_rate.txt, tools/valu_rate.hip): v_max3_i32, v_add_u32_sdwa, v_perm_b32,
-# v_alignbyte_b32, v_mov_b32_dpp, v_pk_*_i16 issue at one wave-instruction per 4.2 SIMD cycles at every occupancy
-# (half rate: 16 lanes per clock); only plain v_add_u32 / v_add_f32 approach the SIMD-32 rate (2.3-2.6 cycles).
-VALU_CYCLES_PER_INST = 4.2
+# Measured on MI355X (profiles/r04_valu_rate3.txt, tools/valu_rate3.hip): the band kernel's ACTUAL step — 16 x {v_add_u32_sdwa,
+# v_max3_i32} in a dependent chain, 4 v_perm_b32, 4 v_alignbyte_b32, two DPP edge exchanges, the LDS reads — issues in 205 SIMD
+# cycles per 44 instructions at two waves per SIMD (the kernels' occupancy): 4.65 cycles per wave-instruction (independent
+# instructions of the same opcodes: 4.2-4.3, profiles/r03_valu_rate2.txt; one wave alone 5.7; only plain VOP2 adds reach 2.6).
+VALU_CYCLES_PER_INST = 4.65
 DP_INSTS_PER_CELL_FLOOR = 2.25      # v_add_u32_sdwa + v_max3_i32 per cell + one v_perm_b32 per four cells
-PROFILE_TAG = "r03"                 # profiles/<tag>[_cfgN]_pmc_summary.json: the PMC passes of this same command (config N)
+PROFILE_TAG = "r04"                 # profiles/<tag>[_cfgN]_pmc_summary.json: the PMC passes of this same command (config N)
 UNIT_LOCI = 1000                    # one instance of a BASELINE config 2 / 3 batch
 # the five DP kernels of a call: (name, strk_stats field with its HIP-event duration)
 DP_KERNELS = (("k_dp_band", "band_kernel_ms"), ("k_dp_band_wide", "band_wide_kernel_ms"), ("k_dp_all", "dp_kernel_ms"),

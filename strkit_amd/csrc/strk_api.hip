@@ -162,12 +162,19 @@ constexpr int kDefaultWindow = 8;
 enum { kEvStart = 0, kEvHead, kEvBand, kEvWide, kEvPre, kEvExact, kEvLong, kEvGeneric, kEvEnd, kNumEvents };
 constexpr int kBandProbationReads = 2048;
 // default half-widths of the candidate window, see g_win_level.  A search that converges at once scores start +- 4, so +-4 is
-// the floor; it holds where the estimate round(|tr| / |motif|) is never off by a size, i.e. for long motifs (tools/window_need.py
-// on BASELINE config 4: motifs of 11+ bases never need more, 7-10 bases in 0.7 % of the loci, 5-6 bases in 6 %, 3-4 in 27 %).
+// the floor of the TABLE; tools/window_need.py (BASELINE config 4): motifs of 11+ bases never need more, 7-10 bases in 0.7 % of
+// the loci, 5-6 bases in 6 %, 3-4 in 27 %.  Levels 4 and 5 exist for the long-motif buckets but are switched off (kWinMinLevel):
+// measured in round 4 on config 4's shard (tools/cfg_probe.py, STRKIT_AMD_WINDOW_B), a narrower TABLE puts the band into a
+// narrower class, and what that class lacks is the slack the certificate needs — +-6 everywhere 6.40 ms per call, +-5 for motifs
+// of 7+ bases 6.34 ms (15 000 certificate failures per call instead of 500), +-4: 8.08 ms (62 000 failures).  The cells a narrow
+// window saves are taken by laying the BAND around the table's inner candidates instead (strk_search.h: BandTune), which keeps
+// the table's outer entries for the searches that the caller's feedback moves.
 // The short-motif buckets stop at +-6: +-5 was tried there in round 3 (the search from a start the feedback moved by one size
 // then ends at the window's edge, 780 reads per 10 000-locus call turn out uncertain: 205 M reads/s instead of 221 M).
 constexpr int kWindowLevels[kWinLevels] = {4, 5, 6, 8, 11, 15};
-constexpr int kWinMinLevel[kWinBuckets] = {2, 2, 2, 0, 0};   // narrowest level a motif-length bucket may settle at
+constexpr int kWinMinLevel[kWinBuckets] = {2, 2, 2, 2, 2};   // narrowest level a motif-length bucket may settle at
+// defaults of BandTune (strk_search.h): the band is laid around the table's middle +- kBandSpanW candidate sizes
+constexpr int kBandSpanW = 64, kBandSlackM8 = 0;
 // Scratch pool (int32 units): kLongWaves slots of kLongSlotInts for k_dp_long (one per resident wave; a slot
 // holds the backward row of all column tiles + two boundary columns: windows up to ~16 kb), then 16 Mi
 // ints of H rows for the generic kernel.  448 MiB of the 288 GB, allocated once per context.
@@ -243,6 +250,11 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
     a.list_stride = list_stride;
     static const int dbg = getenv("STRKIT_AMD_DBG") ? atoi(getenv("STRKIT_AMD_DBG")) : 0;
     a.dbg = dbg;
+    // tuning aids: STRKIT_AMD_SPAN_W / STRKIT_AMD_SLACK_M8 override where the forward band lies (strk_search.h: BandTune)
+    static const int span_w = getenv("STRKIT_AMD_SPAN_W") ? atoi(getenv("STRKIT_AMD_SPAN_W")) : kBandSpanW;
+    static const int slack_m8 = getenv("STRKIT_AMD_SLACK_M8") ? atoi(getenv("STRKIT_AMD_SLACK_M8")) : kBandSlackM8;
+    a.band_tune.span_w = std::max(0, span_w);
+    a.band_tune.slack_m8 = std::max(0, slack_m8);
     a.end_flags = end_flags;
     a.window = window;
     for (int k = 0; k < kWinBuckets; ++k) a.window_b[k] = c->p_window_b[k] > 0 ? c->p_window_b[k] : window;
@@ -468,10 +480,11 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
             if (n_loci_k == 0) continue;
             const int level = std::max(kWinMinLevel[k], g_win_level[k].load(std::memory_order_relaxed));
             // a handful of misses costs less (one short extra round) than a wider window for every read does
-            if (n_miss > std::max(2, n_loci_k / 250)) {
+            // (small calls: two loci of 250 already are 0.8 %, and a window-miss round on long windows costs as much as the call)
+            if (n_miss > std::max(1, n_loci_k / 250)) {
                 if (level < kWinLevels - 1) g_win_level[k].store(level + 1, std::memory_order_relaxed);
                 g_win_quiet[k].store(level < kWinStartLevel ? -56 : 0, std::memory_order_relaxed);   // a failed narrow window is not retried soon
-            } else if (n_miss > std::max(1, n_loci_k / 1000)) {   // more than one locus in a thousand: not a quiet call
+            } else if (n_miss > n_loci_k / 1000) {   // more than one locus in a thousand: not a quiet call
                 g_win_quiet[k].store(0, std::memory_order_relaxed);
             } else if (g_win_quiet[k].fetch_add(1, std::memory_order_relaxed) + 1 >= (level > kWinStartLevel ? 64 : 8) && level > kWinMinLevel[k]) {
                 g_win_level[k].store(level - 1, std::memory_order_relaxed);

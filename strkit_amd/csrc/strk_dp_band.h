@@ -339,7 +339,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     }
     const int ndb = nfl + ntr + nfr;
     // (k_plan listed the item under this class: band_geometry's search over the classes need not be repeated)
-    const BandGeo geo = band_geometry_of_class(BC, nfl, ntr, m, lo, max(n, 1));
+    const BandGeo geo = band_geometry_of_class(BC, nfl, ntr, m, lo, max(n, 1), a.band_tune);
     const int rowsP = act ? nfl + (lo + n - 1) * m : 0;
     const int rowsT = act ? nfr : 0;
     const bool dbBeg = a.end_flags & 1, dbEnd = a.end_flags & 2, cBeg = a.end_flags & 4, cEnd = a.end_flags & 8;

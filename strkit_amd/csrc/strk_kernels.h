@@ -102,6 +102,7 @@ struct KArgs {
     int32_t max_iters, lsr, step, tie_last;  // search parameters (speculative search in k_dp_all)
     int32_t band_mode;    // 1: eligible reads go through k_dp_band first (strk_search.h, "Banded scoring")
     int32_t band_limit;   // only reads with index < band_limit are eligible (a context on probation tries the band on a sample)
+    BandTune band_tune;   // where the forward band lies (strk_search.h: band_geometry)
     uint8_t* exact;       // [n_reads] 1: the read's table holds exact scores, 0: band lower bounds
     int32_t dbg;          // profiling aid (env STRKIT_AMD_DBG, results are wrong when set): 1 no forward pass, 2 no backward
                           //    pass, 4 no in-kernel search, 8 no fork rows
@@ -290,7 +291,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
     const unsigned long long ndb = (unsigned long long)nfl + ntr + nfr;
     int band_list = -1;   // >= 0: the read goes to the band kernel first
     if (a.band_mode && mode == 0 && n > 0 && n <= kTableMax && !force_generic && r < a.band_limit) {
-        const BandGeo geo = band_geometry(nfl, ntr, nfr, m, lo, n);
+        const BandGeo geo = band_geometry(nfl, ntr, nfr, m, lo, n, a.band_tune);
         if (geo.ok) band_list = kBandClass0 + geo.cls;
     }
     if (a.exact && gid < n_items && n > 0) a.exact[r] = band_list < 0;

@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRK_RE
                     const int nfl = a.nfl[rp], ntr = a.ntr[rp], nfr = a.nfr[rp];
                     const int m = a.motif_off[l + 1] - a.motif_off[l];
                     const int wlo = a.win_lo[r], wn = min(a.win_n[r], 64);
-                    const BandGeo geo = band_geometry(nfl, ntr, nfr, m, wlo, wn);
+                    const BandGeo geo = band_geometry(nfl, ntr, nfr, m, wlo, wn, a.band_tune);
                     const int flags = a.end_flags;
                     auto ub = [&](int k) { return band_ub(geo, nfl, ntr, nfr, m, wlo + k, flags); };
                     const CertResult cr = search_replay_cert(start, p.step, p.lsr, p.max_iters, p.tie_last,

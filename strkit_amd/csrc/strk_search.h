@@ -157,17 +157,44 @@ constexpr int kBandFlyMaxFlank = 192;   // on-the-fly rows: 256 staged bytes hol
 constexpr int kBandRowSlack = 96;    // prefix rows a band item may have beyond |db|
 constexpr int kBandNarrowSlack = 22; // diagonals a 12-diagonal class keeps free on each side of the candidates' span, at least
 
-STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, int32_t lo, int32_t n) {
+// Where the forward band lies (round 4): the table holds the candidates est - W .. est + W, but a search that converges at once
+// only ever scores est +- 4 (seed windows [s - 3, s + 3], [s + 1, s + 4], [s - 4, s - 1]); the outer entries are there for the
+// reads whose start the caller's feedback moved.  The band is therefore laid around the corner diagonals of the INNER candidates
+// only — the table's middle +- span_w sizes — with the slack rule below on each side; an outer candidate still gets its fork row and
+// a sound (S_band, band_ub) pair, just with less slack (its corner sits nearer the band's edge), and a search that needs it and
+// cannot certify it is re-scored exactly as before.  What that buys: a window of +-6 sizes of a 6-base motif spans 73 diagonals and
+// took the 128-diagonal class; its inner +-4 span 49 and fit the 96-diagonal one.
+// Slack per side: |db| / 32 (a HiFi read's score deficit grows with its length), at least 12 (22 in the 12-diagonal classes),
+// and slack_m8 / 8 diagonals per motif base: a search window that does not hold the best size has its maximum about 7 |motif| under
+// the perfect score (one copy too many or too few), and the 2 * len(diagonal) bound of its inexact entries must stay below that.
+struct BandTune {
+    int32_t span_w;     // half-width (in candidate sizes) of the table's middle that the band is laid around
+    int32_t slack_m8;   // slack per side >= slack_m8 * |motif| / 8 diagonals
+};
+constexpr BandTune kBandTuneNone = {64, 0};   // the whole table, no motif term (the geometry of rounds 2-3)
+
+// the inner candidates [c_lo, c_hi] of a table [lo, lo + n)
+STRK_HD void band_inner(int32_t lo, int32_t n, int32_t span_w, int32_t* c_lo, int32_t* c_hi) {
+    int32_t t = (n - 1) / 2 - span_w;
+    if (t < 0) t = 0;
+    *c_lo = lo + t;
+    *c_hi = lo + n - 1 - t;
+}
+
+STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, int32_t lo, int32_t n, BandTune tune = kBandTuneNone) {
     BandGeo b = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t ndb = (int64_t)nfl + ntr + nfr;
     if (nfl < 1 || nfr < 1 || nfr > kBandMaxFlank || m < 1 || m > 256 || n < 1 || n > 32) return b;
-    const int64_t e_lo = (int64_t)ntr - (int64_t)(lo + n - 1) * m, e_hi = (int64_t)ntr - (int64_t)lo * m;
+    int32_t c_lo, c_hi;
+    band_inner(lo, n, tune.span_w, &c_lo, &c_hi);
+    const int64_t e_lo = (int64_t)ntr - (int64_t)c_hi * m, e_hi = (int64_t)ntr - (int64_t)c_lo * m;
     const int64_t span_lo = e_lo < 0 ? e_lo : 0, span_hi = e_hi > 0 ? e_hi : 0;
     // slack on each side: the certificate needs about half the score deficit of the read, and a HiFi read's deficit grows
     // with its length (~0.3 % errors at 9-12 points each): |db| / 32 keeps the certificate failures of kilobase windows
     // (long motifs, BASELINE config 4) at a few per cent
     int64_t smin = ndb >> 5;
     if (smin < 12) smin = 12;
+    if (smin < ((int64_t)tune.slack_m8 * m >> 3)) smin = (int64_t)tune.slack_m8 * m >> 3;
     const int64_t rows = (int64_t)nfl + (int64_t)(lo + n - 1) * m;
     int32_t cls = -1;
     for (int32_t k = 0; k < kNumBandClasses && cls < 0; ++k) {   // narrowest class that holds band and window: 96, 128, 192, 256, ...
@@ -202,9 +229,11 @@ STRK_HD BandGeo band_geometry(int32_t nfl, int32_t ntr, int32_t nfr, int32_t m, 
 
 // The geometry of an item that band_geometry has already put into class `cls` (k_plan did; the band kernel works on that class's
 // list): the same numbers without the search over the classes, in 32-bit arithmetic (the class limits bound every length).
-STRK_HD BandGeo band_geometry_of_class(int32_t cls, int32_t nfl, int32_t ntr, int32_t m, int32_t lo, int32_t n) {
+STRK_HD BandGeo band_geometry_of_class(int32_t cls, int32_t nfl, int32_t ntr, int32_t m, int32_t lo, int32_t n, BandTune tune = kBandTuneNone) {
     BandGeo b;
-    const int32_t e_lo = ntr - (lo + n - 1) * m, e_hi = ntr - lo * m;
+    int32_t c_lo, c_hi;
+    band_inner(lo, n, tune.span_w, &c_lo, &c_hi);
+    const int32_t e_lo = ntr - c_hi * m, e_hi = ntr - c_lo * m;
     const int32_t span_lo = e_lo < 0 ? e_lo : 0, span_hi = e_hi > 0 ? e_hi : 0;
     const int32_t wd = band_class_wd(cls);
     const int32_t extra = wd - (span_hi - span_lo + 1);

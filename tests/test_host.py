@@ -373,7 +373,7 @@ def test_contiguous_block_dealing_gives_every_rank_one_balanced_run():
 def test_class_known_band_geometry_equals_the_search_over_the_classes(tmp_path):
     """band_geometry_of_class (what the band kernels recompute per item from its class) must give exactly what band_geometry
     (k_plan: the search over the eight classes) gave for every eligible item: same band, same column range.  Host build of
-    strk_search.h, 3 million random shapes incl. long windows and every window half-width."""
+    strk_search.h, 3 million random shapes incl. long windows, every window half-width and every band placement (BandTune)."""
     import shutil
     import subprocess
     if shutil.which("g++") is None:
@@ -394,11 +394,12 @@ int main() {
         int W = 3 + rng() %% 13;
         int lo = std::max(0, est - W), n = std::min(32, est + W - lo + 1);
         int ntr = std::max(0, est * m + (int)(rng() %% 41) - 20);
-        strk::BandGeo a = strk::band_geometry(nfl, ntr, nfr, m, lo, n);
+        strk::BandTune tune = {(int)(rng() %% 3 == 0 ? 64 : 3 + rng() %% 5), (int)(rng() %% 2 ? 0 : rng() %% 33)};
+        strk::BandGeo a = strk::band_geometry(nfl, ntr, nfr, m, lo, n, tune);
         if (!a.ok) continue;
         ++n_ok;
         if (strk::band_class_fly(a.cls) && (nfl > strk::kBandFlyMaxFlank || m > strk::kBandFlyMaxMotif)) ++fly_limits;
-        strk::BandGeo b = strk::band_geometry_of_class(a.cls, nfl, ntr, m, lo, n);
+        strk::BandGeo b = strk::band_geometry_of_class(a.cls, nfl, ntr, m, lo, n, tune);
         if (a.cls != b.cls || a.G != b.G || a.wd != b.wd || a.dlo != b.dlo || a.bwd != b.bwd || a.bdlo != b.bdlo ||
             a.cmin != b.cmin || a.ncol != b.ncol) ++bad;
     }
