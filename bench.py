@@ -46,6 +46,7 @@ N_SIMD = 256 * 4
 # instructions of the same opcodes: 4.2-4.3, profiles/r03_valu_rate2.txt; one wave alone 5.7; only plain VOP2 adds reach 2.6).
 VALU_CYCLES_PER_INST = 4.65
 DP_INSTS_PER_CELL_FLOOR = 2.25      # v_add_u32_sdwa + v_max3_i32 per cell + one v_perm_b32 per four cells
+PROFILE_TAG_PREV = "r03"
 PROFILE_TAG = "r04"                 # profiles/<tag>[_cfgN]_pmc_summary.json: the PMC passes of this same command (config N)
 UNIT_LOCI = 1000                    # one instance of a BASELINE config 2 / 3 batch
 # the five DP kernels of a call: (name, strk_stats field with its HIP-event duration)
@@ -120,12 +121,20 @@ def cpu_baseline(cfg: int, sample_loci: int, pool, cores: int) -> dict:
             "reads_per_s_per_core": best["reads_per_s_per_core"], "gcups": best["gcups"], "scalar": out["scalar"], "simd": out.get("simd")}
 
 
+def pmc_file(cfg: int = 2) -> str | None:
+    """profiles/<tag>[_cfgN]_pmc_summary.json of this round, else the previous round's (named in the output)."""
+    for tag in (PROFILE_TAG, PROFILE_TAG_PREV):
+        name = f"{tag}_pmc_summary.json" if cfg == 2 else f"{tag}_cfg{cfg}_pmc_summary.json"
+        if os.path.exists(os.path.join(ROOT, "profiles", name)):
+            return name
+    return None
+
+
 def pmc_summary(kernel: str, cfg: int = 2) -> dict | None:
     """Per-launch PMC readings of `kernel` from the committed rocprofv3 passes of this same command on config `cfg`
     (profiles/README.md; separate --pmc passes, FETCH_SIZE / WRITE_SIZE in KiB)."""
-    name = f"{PROFILE_TAG}_pmc_summary.json" if cfg == 2 else f"{PROFILE_TAG}_cfg{cfg}_pmc_summary.json"
     try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
+        with open(os.path.join(ROOT, "profiles", pmc_file(cfg))) as f:
             return json.load(f)[kernel]
     except Exception:  # noqa: BLE001
         return None
@@ -152,7 +161,7 @@ def valu_block(kname: str, cfg: int, k_ms: float, cells_launch: float) -> dict |
         return None
     clock_ghz = pmc.get("clock_ghz", 2.3)
     floor_ms = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / N_SIMD / (clock_ghz * 1e9) * 1e3
-    return {"valu_from_profile": f"profiles/{PROFILE_TAG}{'' if cfg == 2 else f'_cfg{cfg}'}_pmc_summary.json",
+    return {"valu_from_profile": f"profiles/{pmc_file(cfg)}",
             "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES_PER_INST,
             "valu_clock_ghz": clock_ghz, "floor_ms": floor_ms,
             "profile_kernel_ms": pmc.get("unoverlapped_avg_us", 0.0) / 1e3,

@@ -205,7 +205,10 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
         asm volatile("" : "+v"(nb), "+v"(sym2));                                                   \
         if (LMAX && !BWD) {                                                                        \
             lastmax = max(lastmax + g, houtL);      /* (kept shifted by g * row: add and max per step) */ \
-            if ((TT) == G - 2) lastmax = kNegInf;   /* (scalar test) the last lane has just finished row 0 */ \
+            /* the last lane has just finished row 0 at step G - 2 = tTop, which only ever runs as a boundary step (a wave-uniform  \
+               test in the plain steps became s_cselect vcc + v_cndmask: 23 cycles for a VOP2 select whose VCC no VALU compare \
+               has just written, profiles/r04_valu_rate3.txt) */                                    \
+            if ((EDGE) && (TT) == G - 2) lastmax = kNegInf;                                        \
         }                                                                                          \
         _Pragma("unroll") for (int q = 0; q + 1 < NQ; ++q) sel[q] = __builtin_amdgcn_alignbyte(sel[q + 1], sel[q], 1); \
         sel[NQ - 1] = __builtin_amdgcn_alignbyte(nb, sel[NQ - 1], 1);                              \
@@ -246,7 +249,11 @@ __device__ __forceinline__ void band_pass(const BandCtx& x, const uint8_t* rowsy
     // its body makes the compiler copy the two row arrays once per pair)
     auto advance = [&]() {
         psym += 2;
-        if (FLY && psym >= flyEnd) psym -= x.flyP;
+        if (FLY) {   // psym -= flyP when it has passed flyEnd — without a select (sub, ashr, and, sub: four fast-class instructions)
+            int past = (int)(flyEnd - psym - 1) >> 31;   // all ones when psym >= flyEnd
+            asm volatile("" : "+v"(past));                  // (or the compiler folds shift + and back into v_cmp + v_cndmask)
+            psym -= x.flyP & past;
+        }
         asm volatile("" : "+v"(psym));
         pnb += BWD ? -2 : 2;
         asm volatile("" : "+v"(pnb));

@@ -34,6 +34,15 @@ __global__ void __launch_bounds__(256) k_cnd(int* out, unsigned long long* stamp
         // a select as the compiler emits it in a loop: compare + cndmask pairs
         if (KIND == 4) { REP64(asm volatile("v_cmp_gt_i32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_gt_i32 vcc, %4, %5\n v_cndmask_b32 %6, %6, %7, vcc"
                                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "vcc");) }
+        // VCC written by the SCALAR unit (a wave-uniform condition the compiler turned into a select): s_cselect_b64 vcc + v_cndmask
+        if (KIND == 5) { REP64(asm volatile("s_cmp_lg_u32 %8, 29\n s_cselect_b64 vcc, -1, 0\n v_cndmask_b32 %0, %0, %1, vcc\n v_add_u32 %2, %2, %3\n v_add_u32 %4, %4, %5\n v_add_u32 %6, %6, %7"
+                                            : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "s"(i) : "vcc", "scc");) }
+        // v_cmp, three unrelated instructions, then the v_cndmask that reads its VCC
+        if (KIND == 6) { REP64(asm volatile("v_cmp_gt_i32 vcc, %0, %1\n v_add_u32 %2, %2, %3\n v_add_u32 %4, %4, %5\n v_add_u32 %6, %6, %7\n v_cndmask_b32 %0, %0, %1, vcc"
+                                            : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "vcc");) }
+        // the same select without VCC: mask = (x - y) >> 31 (arithmetic), d = (d & ~mask) | (e & mask) ... here: d -= e & mask (four fast-class instructions)
+        if (KIND == 7) { REP64(asm volatile("v_sub_u32 %2, %0, %1\n v_ashrrev_i32 %2, 31, %2\n v_and_b32 %4, %2, %5\n v_sub_u32 %6, %6, %4"
+                                            : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d + e + f + g + h + p + q + r + s;
@@ -158,6 +167,9 @@ int main() {
     CND(2, "v_cndmask_b32_e64 (SGPR-pair mask, dst != srcs)")
     CND(3, "v_and_b32 with a mask register (replacement)")
     CND(4, "v_cmp_gt_i32 + v_cndmask_b32 pairs (per instr.)")
+    CND(5, "s_cselect_b64 vcc + v_cndmask + 3 v_add (x4/grp)")
+    CND(6, "v_cmp, 3 v_add, v_cndmask (5 instr. per 4 counted)")
+    CND(7, "sub, ashr, and, sub: select without VCC")
     const int siters = 4000;   // pairs of steps
 #define STEP(K, N, INSTS) measure(N, (INSTS) * 2.0 * siters, 2.0 * siters, [&](int blocks, bool warm) { hipLaunchKernelGGL(k_step<K>, dim3(blocks), dim3(256), 0, 0, d_out, d_st, warm ? 50 : siters); }, d_out, d_st, h_st);
     STEP(0, "band step, 44 VALU + 3 LDS reads + waitcnt", 44.0)
