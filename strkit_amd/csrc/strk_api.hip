@@ -121,7 +121,7 @@ struct DevBuf {
 struct strk_ctx {
     int device = 0;
     // workspace
-    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, band_recs, counters, scratch, state_i32, state_f64, spec, rhash, rep, exact;
+    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, band_recs, band_recs_w, counters, scratch, state_i32, state_f64, spec, rhash, rep, exact;
     DevBuf win_lo2, win_n2, tab_off2, table2, items;
     // staging for the host-buffer entry points
     DevBuf in_seqs, in_seq_off, in_nfl, in_ntr, in_nfr, in_est, in_read_off, in_motifs, in_motif_off;
@@ -185,6 +185,9 @@ constexpr size_t kScratchInts = kLongWaves * kLongSlotInts + ((size_t)16 << 20);
 // device layout of the `counters` buffer: int32[kCntTotal] | pad | u64 cells | u64 scratch_used
 constexpr size_t kCellsOff = 64 * sizeof(int32_t);
 constexpr size_t kCountersBytes = kCellsOff + 10 * sizeof(unsigned long long);   // cells, scratch_used, band / exact / wide-band / long-kernel bytes, cells per kernel (kCell*)
+// behind them, zeroed with them but not copied back: k_plan's census of the wide band classes and k_sort_wide's cursors
+constexpr size_t kWideHistOff = (kCountersBytes + 63) & ~(size_t)63;
+constexpr size_t kCountersAllBytes = kWideHistOff + 2 * kNumWideLists * 256 * sizeof(int32_t);
 
 int check_params(const strk_params* p, strk_params* out) {
     if (!p) return fail(STRK_E_INVALID, "params is NULL");
@@ -212,7 +215,8 @@ int ensure_workspace(strk_ctx* c, int n_reads, int n_loci, size_t table_ints, si
     if ((rc = c->table.ensure(std::max<size_t>(table_ints, 1) * 4))) return rc;
     if ((rc = c->cls_list.ensure((size_t)kNumLists * std::max<size_t>(n_items, 1) * 2 * 4))) return rc;
     if ((rc = c->band_recs.ensure((size_t)kNumBandClasses * std::max<size_t>(n_items, 1) * 3 * sizeof(int4)))) return rc;
-    if ((rc = c->counters.ensure(kCountersBytes))) return rc;
+    if ((rc = c->counters.ensure(kCountersAllBytes))) return rc;
+    if ((rc = c->band_recs_w.ensure((size_t)kNumBandClasses * std::max<size_t>(n_items, 1) * 3 * sizeof(int4)))) return rc;
     if ((rc = c->state_i32.ensure(nl * 4 * 4))) return rc;
     if ((rc = c->state_f64.ensure(nl * 8))) return rc;
     if ((rc = c->spec.ensure(nr * 16))) return rc;
@@ -240,6 +244,8 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
     a.table = c->table.as<int32_t>();
     a.cls_list = c->cls_list.as<int32_t>();
     a.band_recs = c->band_recs.as<int4>();
+    a.band_recs_w = a.band_recs;   // (k_sort_wide's copy when that kernel is launched: enqueue_scoring)
+    a.wide_hist = reinterpret_cast<int32_t*>(c->counters.as<char>() + kWideHistOff);
     a.counters = c->counters.as<int32_t>();
     a.cells = reinterpret_cast<unsigned long long*>(c->counters.as<char>() + kCellsOff);
     a.scratch_used = a.cells + 1;
@@ -275,7 +281,17 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
 // plan (classification) + all DP kernels for the reads in `items` (NULL = all reads).
 void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_items, int n_items, int force_generic,
                      hipStream_t st, bool time_dp, const ReplayArgs* pre_replay = nullptr) {
-    hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, a, mode, d_items, n_items, force_generic);
+    // Longest-first order of the wide band classes (k_sort_wide) pays when their chunks are few against the ~2 000 resident waves —
+    // the launch then lasts as long as its longest chunk and whatever was started late (BASELINE config 5 at one GPU's share:
+    // 6 400 chunks, k_dp_band_wide 3.77 -> 3.38 ms) — and costs its census (k_plan) and a small kernel when they are many
+    // (config 4's shard, 16 000 chunks: +0.1 ms for nothing).  Decided by the previous call's queue; a first call sorts.
+    const bool hist0 = mode == 0 && c->hist_valid && c->hist_band_mode == a.band_mode;
+    const bool sort_wide = a.band_mode && mode == 0 && !force_generic && (!hist0 || (c->hist_wide_chunks > 0 && c->hist_wide_chunks <= 8192));
+    {
+        KArgs ap = a;
+        if (!sort_wide) ap.wide_hist = nullptr;
+        hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, ap, mode, d_items, n_items, force_generic);
+    }
     static const int tune = getenv("STRKIT_AMD_DP_BLOCKS") ? atoi(getenv("STRKIT_AMD_DP_BLOCKS")) : 0;   // tuning aid
     // A call that shares the device with other calls in flight takes fifteen sixteenths of the CU slots per kernel: the free
     // slots are what lets the LDS-holding tail kernels of one call (k_dp_band_wide, k_dp_all, k_dp_long) start while another
@@ -302,7 +318,14 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
         hipLaunchKernelGGL(k_dp_band, dim3(band_blocks), dim3(256), 0, st, a);
     }
     if (time_dp) (void)hipEventRecord(c->ev[kEvBand], st);
-    if (band) hipLaunchKernelGGL(k_dp_band_wide, dim3(predicted_blocks(c->hist_wide_chunks, band_blocks)), dim3(256), 0, st, a);   // long windows
+    if (band) {   // long windows
+        KArgs aw = a;
+        if (sort_wide) {
+            hipLaunchKernelGGL(k_sort_wide, dim3(64), dim3(256), 0, st, a, c->band_recs_w.as<int4>());
+            aw.band_recs_w = c->band_recs_w.as<int4>();
+        }
+        hipLaunchKernelGGL(k_dp_band_wide, dim3(predicted_blocks(c->hist_wide_chunks, band_blocks)), dim3(256), 0, st, aw);
+    }
     if (time_dp) (void)hipEventRecord(c->ev[kEvWide], st);
     // first k_replay pass (strk_replay.h): as far as the certified band tables carry each locus, before the exact kernels
     if (band && pre_replay) hipLaunchKernelGGL(k_replay, dim3(a.n_loci), dim3(64), 0, st, a, *pre_replay);
@@ -396,7 +419,7 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
         ~InFlight() { if (!keep) g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
     } in_flight;
     HIP_TRY(hipEventRecord(c->ev[kEvStart], st));
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersBytes, st));
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, kCountersAllBytes, st));
     if (a.rhash) hipLaunchKernelGGL(k_hash, dim3((b->n_reads + 31) / 32), dim3(256), 0, st, a);   // eight lanes per read
     ReplayArgs rp_pre = rp;
     rp_pre.pre_exact = 1;
@@ -469,6 +492,8 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
     fprintf(stderr, "[phase ticks/64] header %d stage %d (of which pads %d, window bytes %d) tables %d bwd %d fwd %d epilogue %d\n", c->h_counters[48],
             c->h_counters[49] + c->h_counters[54] + c->h_counters[55], c->h_counters[55], c->h_counters[54], c->h_counters[50], c->h_counters[51],
             c->h_counters[52], c->h_counters[53]);
+    fprintf(stderr, "[phase] longest chunk %d ticks/64 (%.3f ms at 2.4 GHz), most rows in a chunk %d, chunks %d\n", c->h_counters[45],
+            c->h_counters[45] * 64.0 / 2.4e6, c->h_counters[46], c->h_counters[47]);
 #endif
     int n_band_reads = 0;
     for (int k = 0; k < kNumBandClasses; ++k) n_band_reads += c->h_counters[kCntClass0 + kBandClass0 + k];

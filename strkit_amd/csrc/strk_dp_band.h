@@ -315,6 +315,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     const int lane = threadIdx.x & 63;
 #ifdef STRK_PHASE_TIMING
     unsigned long long tphase = __builtin_readcyclecounter();
+    const unsigned long long tchunk = tphase;
 #endif
     int lig_ = lane & (G - 1);
     // (opaque per chunk: what a pass derives from the lane index and the class's constants — sixteen clamped row-0 values of
@@ -458,6 +459,17 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     nextB();
     STRK_PHASE(2);
 
+    // Long-window classes: a chunk of 12 000 rows is the critical path of a launch that does not fill the chip many times over
+    // (BASELINE config 5 at one GPU's share: the longest chunk alone ran 3.0 of the kernel's 3.95 ms, census of the phase-timing
+    // build) — and it ran at HALF speed, sharing its SIMD's issue slots with the wave of a short chunk.  Priority goes by rows: the
+    // long chunk takes the issue slots it can use (arbitration is by priority, then age), its partner gets the rest; the work is the
+    // same, the longest chunk's latency is not.
+    if (FLY && !(a.dbg & 32)) {   // (dbg 32: profiling aid, no priorities)
+        const int rmax = wave_max_over_groups(rowsP);
+        if (rmax >= 11264) __builtin_amdgcn_s_setprio(3);
+        else if (rmax >= 8192) __builtin_amdgcn_s_setprio(2);
+        else if (rmax >= 5120) __builtin_amdgcn_s_setprio(1);
+    }
     BandCtx x;
     x.lig = lig; x.first = first; x.last = last; x.notFirst = first ? 0 : -1; x.notLast = last ? 0 : -1; x.selb = selb;
     asm volatile("" : "+v"(x.notFirst), "+v"(x.notLast));   // plain AND masks: operands of the DPP shifts, not selects
@@ -475,6 +487,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     x.tbl = s_tbl;
     band_pass<G, D, false, FLY, LMAX>(x, cp, (run && !(a.dbg & 1)) ? rowsP : 0, geo.dlo, dbBeg, cBeg, (a.dbg & 8) ? 0 : nEff, nfl + lo * m, m, geo.cmin, geo.ncol, comb, b0col, lmaxA);
     wave_lds_sync();
+    if (FLY) __builtin_amdgcn_s_setprio(0);
     STRK_PHASE(4);
     if (run) {
         for (int k = lig; k < n; k += G) {
@@ -529,6 +542,16 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
     }
     wave_lds_sync();
     STRK_PHASE(5);
+#ifdef STRK_PHASE_TIMING
+    {   // the longest chunk of the launch (ticks / 64), the most rows a chunk had, chunks, and the sum of their longest items' rows
+        const int rows_ = wave_max_over_groups(act ? nfl + (lo + n - 1) * m : 0);
+        if (lane == 0) {
+            atomicMax(&a.counters[45], (int)((tphase - tchunk) >> 6));
+            atomicMax(&a.counters[46], rows_);
+            atomicAdd(&a.counters[47], 1);
+        }
+    }
+#endif
 }
 
 // Two kernels so that the common short classes (8 and 16 lanes per read) are not register-allocated together with the long-
@@ -593,7 +616,7 @@ __device__ __forceinline__ void band_kernel_body(const KArgs& a) {
         else if (c < e3) { cls = C3; it = (c - e2) * per23 + lane / G23; cnt = n3_; G_ = G23; }
         act = it < cnt;
         if (act) {
-            const int4* rec = a.band_recs + ((size_t)cls * a.list_stride + it) * 3;
+            const int4* rec = (SET ? a.band_recs_w : a.band_recs) + ((size_t)cls * a.list_stride + it) * 3;
             q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
         }
         return G_;   // lanes per item of that chunk

@@ -79,6 +79,9 @@ struct KArgs {
     int32_t* cls_list;    // [kNumLists * list_stride * 2]  (read, chunk start) pairs
     int4* band_recs;      // [kNumBandClasses * list_stride * 3]  everything a band item needs, written by k_plan:
                           //   (read, locus, nfl, ntr) (nfr, m, lo, n) (seq_off lo, seq_off hi, motif_off, est_cn)
+    int4* band_recs_w;    // the records k_dp_band_wide reads: band_recs, or k_sort_wide's copy of the four wide classes, longest first
+    int32_t* wide_hist;   // [2][kNumWideLists][256] items of the wide band classes by prefix rows / 64 (k_plan), then the cursors
+                          //    k_sort_wide hands positions out with (zeroed with the counters)
     int32_t* counters;    // see Counter enum
     unsigned long long* cells;  // DP cells executed; cells[2] / cells[3]: algorithmic bytes (|window| + 16 per read) of the
                                 // items routed to the band kernels / to the exact kernels by k_plan; cells[4] / cells[5]: the part
@@ -105,7 +108,7 @@ struct KArgs {
     BandTune band_tune;   // where the forward band lies (strk_search.h: band_geometry)
     uint8_t* exact;       // [n_reads] 1: the read's table holds exact scores, 0: band lower bounds
     int32_t dbg;          // profiling aid (env STRKIT_AMD_DBG, results are wrong when set): 1 no forward pass, 2 no backward
-                          //    pass, 4 no in-kernel search, 8 no fork rows
+                          //    pass, 4 no in-kernel search, 8 no fork rows, 16 band items in arrival order, 32 no wave priorities
     int32_t ref_mode;     // 1: reference-side scoring (repeats.py:23-43): candidate = fl + motif*i only, the
                           //    table holds (score, end_query) pairs, end_flags must be STRK_DB_END_FREE
 };
@@ -129,6 +132,11 @@ enum Counter {
 constexpr int kWinBuckets = 5;
 __host__ __device__ constexpr int win_bucket(int m) { return m <= 2 ? 0 : (m <= 4 ? 1 : (m <= 6 ? 2 : (m <= 10 ? 3 : 4))); }
 static_assert(kCntTotal <= 48, "counters 48..55 belong to the phase-timing aid, the 64-bit counters start at int 64");
+// wide band classes (k_dp_band_wide: 2, 3, 6, 7) -> 0..3, and rows -> bucket of the longest-first order
+constexpr int kNumWideLists = 4;
+__host__ __device__ constexpr int wide_slot(int band_cls) { return (band_cls & 1) | ((band_cls >> 2) << 1); }
+__host__ __device__ constexpr int wide_slot_class(int slot) { return 2 + (slot & 1) + ((slot >> 1) << 2); }
+__host__ __device__ constexpr int wide_bucket(int rows) { return rows >= (255 << 6) ? 255 : (rows < 0 ? 0 : rows >> 6); }
 // slots of KArgs::cells that split cells[0] by kernel; cell_slot_of_list: the slot of a class list's kernel (-1: generic)
 constexpr int kCellBand = 6, kCellWide = 7, kCellExact = 8, kCellLong = 9;
 __host__ __device__ constexpr int cell_slot_of_list(int c) {
@@ -376,10 +384,54 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
                 rec[0] = make_int4(r, l, nfl, ntr);
                 rec[1] = make_int4(nfr, m, lo, n);
                 rec[2] = make_int4((int)(so & 0xffffffffll), (int)(so >> 32), a.motif_off[l], a.est_cn[r]);
+                if (a.wide_hist && band_class_wide_kernel(band_list - kBandClass0))   // census for the longest-first order (k_sort_wide)
+                    atomicAdd(&a.wide_hist[wide_slot(band_list - kBandClass0) * 256 + wide_bucket(nfl + (lo + n - 1) * m)], 1);
             }
         } else {
             atomicOr(&a.counters[kCntError], kErrScratch);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Longest first: the items of the four wide band classes, re-listed by descending prefix rows (counting sort on rows / 64 from
+// k_plan's census; order inside a bucket is whatever the cursors hand out — results do not depend on it).  A wave of
+// k_dp_band_wide works for milliseconds on one 12 000-row read: the queue must not hold such a chunk back until other waves
+// have nothing left (BASELINE config 5 at one GPU's share: 6 400 chunks for 1 900 waves, class by class but in arrival order
+// inside a class), and two reads that share a wave in lock step should be of one length.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sort_wide(KArgs a, int4* out) {
+    __shared__ int s_start[kNumWideLists][256];   // first position of each bucket in the descending order
+    __shared__ int s_cnt[kNumWideLists];
+    int total = 0;
+    for (int s = 0; s < kNumWideLists; ++s) total += min(a.counters[kCntClass0 + kBandClass0 + wide_slot_class(s)], a.list_stride);
+    if (total == 0) return;
+    {   // 1 024 = 4 lists x 256 buckets: thread t scans list t / 64's buckets (t % 64) * 4 .. + 3 after a per-list suffix sum
+        const int s = threadIdx.x >> 6, q = threadIdx.x & 63;
+        const int* h = a.wide_hist + s * 256;
+        int mine[4], sum = 0;
+        for (int k = 0; k < 4; ++k) { mine[k] = h[255 - (q * 4 + k)]; sum += mine[k]; }   // descending: bucket 255 first
+        // exclusive scan of `sum` over the 64 lanes of this wave (= this list)
+        int incl = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (q >= o) incl += v;
+        }
+        int pos = incl - sum;
+        for (int k = 0; k < 4; ++k) { s_start[s][255 - (q * 4 + k)] = pos; pos += mine[k]; }
+        if (q == 0) s_cnt[s] = min(a.counters[kCntClass0 + kBandClass0 + wide_slot_class(s)], a.list_stride);
+    }
+    __syncthreads();
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+        int s = 0, idx = g;
+        while (idx >= s_cnt[s]) { idx -= s_cnt[s]; ++s; }
+        const int cls = wide_slot_class(s);
+        const int4* rec = a.band_recs + ((size_t)cls * a.list_stride + idx) * 3;
+        const int4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        const int b = wide_bucket(q0.z + (q1.z + q1.w - 1) * q1.y);
+        const int pos = s_start[s][b] + atomicAdd(&a.wide_hist[(kNumWideLists + s) * 256 + b], 1);
+        int4* o = out + ((size_t)cls * a.list_stride + pos) * 3;
+        o[0] = q0; o[1] = q1; o[2] = q2;
     }
 }
 

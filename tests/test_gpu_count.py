@@ -302,3 +302,34 @@ def test_host_entry_point_reads_page_locked_arrays_in_place(gpu_ctx):
     again, _, _ = run()
     for x, y in zip(plain, again):
         assert np.array_equal(x, y)
+
+
+def test_pin_cases_fixture(gpu_ctx):
+    """tests/golden/pin_cases.json through the C ABI: lower-case windows, empty tracts, start 0, IUPAC motifs against wildcards,
+    constructed ties under both tie rules (read side) and the boundary-tie loci of the reference side."""
+    import json
+    import os
+    from strkit_amd.batch import count_loci
+    from strkit_amd.repeat_count_params import RepeatCountParams
+    from strkit_amd.repeats import get_ref_repeat_count
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pin_cases.json")) as f:
+        cases = json.load(f)
+    for name, case in cases.items():
+        if name == "ref_ties":
+            continue
+        b = LocusBatch.from_reads([(l["motif"], [tuple(r) for r in l["reads"]]) for l in case["loci"]], [l["est_cn"] for l in case["loci"]])
+        for tag, tie in (("expected_first_max", 0), ("expected_last_max", 1)):
+            got = count_loci(b, ctx=gpu_ctx, tie_rule=tie)
+            for k, v in case[tag].items():
+                assert got[k].tolist() == v, (name, tag, k)
+    ref = cases["ref_ties"]
+    rc = RepeatCountParams("repalign", 50, 3, 1)
+    k = 0
+    for l in ref["loci"]:
+        for a, tr, c in l["reads"]:
+            for respect in (False, True):
+                res = get_ref_repeat_count(round(len(tr) / len(l["motif"])), tr, a, c, l["motif"], len(tr), 5, rc, respect_coords=respect,
+                                           context=gpu_ctx)
+                assert json.loads(json.dumps(res)) == ref["expected"][k], (l["motif"], respect)
+                k += 1
+

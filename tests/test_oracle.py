@@ -178,6 +178,40 @@ def test_golden_count_cases():
             assert got[k].tolist() == v, (name, k)
 
 
+def test_golden_pin_cases():
+    """tests/golden/pin_cases.json (make_pin_cases.py): the inputs the oracle's open assumptions hinge on — lower-case windows,
+    empty tracts, start 0, IUPAC motifs against wildcards, constructed ties (both tie rules), reference-side boundary ties."""
+    with open(os.path.join(GOLD, "pin_cases.json")) as f:
+        cases = json.load(f)
+    assert set(cases) == {"case", "empty", "start0", "iupac", "ties", "ref_ties"}
+    for name, case in cases.items():
+        if name == "ref_ties":
+            continue
+        b = _golden_batch(case["loci"])
+        for tag, tie in (("expected_first_max", 0), ("expected_last_max", 1)):
+            got = oracle_count(b, tie_rule=tie)
+            for k, v in case[tag].items():
+                assert got[k].tolist() == v, (name, tag, k)
+    # upper- and lower-case windows count alike; the tie cases really depend on the rule
+    c = cases["case"]
+    b = _golden_batch(c["loci"])
+    up = LocusBatch.from_reads([(l["motif"].upper(), [tuple(x.upper() for x in r) for r in l["reads"]]) for l in c["loci"]],
+                               [l["est_cn"] for l in c["loci"]])
+    assert oracle_count(b)["cn"].tolist() == oracle_count(up)["cn"].tolist() == c["expected_first_max"]["cn"]
+    t = cases["ties"]
+    assert all(x != y for x, y in zip(t["expected_first_max"]["cn"], t["expected_last_max"]["cn"]))
+    ref = cases["ref_ties"]
+    k = 0
+    for l in ref["loci"]:
+        for a, tr, cc in l["reads"]:
+            for respect in (False, True):
+                res = oracle.ref_repeat_count(round(len(tr) / len(l["motif"])), tr, a, cc, l["motif"], len(tr), 5, 50, 3, 1,
+                                              respect_coords=respect)
+                assert json.loads(json.dumps(res)) == ref["expected"][k], (l["motif"], respect)
+                k += 1
+    assert k == len(ref["expected"])
+
+
 def test_golden_score_tables():
     with open(os.path.join(GOLD, "score_tables.json")) as f:
         g = json.load(f)
