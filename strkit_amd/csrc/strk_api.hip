@@ -144,6 +144,7 @@ struct strk_ctx {
     // and so delays the band blocks of the calls it overlaps with
     bool hist_valid = false;
     int hist_band_mode = 0, hist_reads = 1, hist_exact_chunks = 0, hist_wide_chunks = 0, hist_long = 0;
+    bool hist_tail_heavy = false;   // the previous call had both band kernels busy (each more than a quarter of the other's cells)
     // one submitted-but-not-finished batched call (strk_submit_loci_device .. strk_finish)
     bool pending = false;
     strk_batch p_batch;
@@ -172,7 +173,11 @@ constexpr int kBandProbationReads = 2048;
 // The short-motif buckets stop at +-6: +-5 was tried there in round 3 (the search from a start the feedback moved by one size
 // then ends at the window's edge, 780 reads per 10 000-locus call turn out uncertain: 205 M reads/s instead of 221 M).
 constexpr int kWindowLevels[kWinLevels] = {4, 5, 6, 8, 11, 15};
-constexpr int kWinMinLevel[kWinBuckets] = {2, 2, 2, 2, 2};   // narrowest level a motif-length bucket may settle at
+// narrowest level a motif-length bucket may settle at.  Motifs of 1-2 bases stay at +-8: their estimate is off by a size for every
+// second base of indel drift (tools/window_need.py, config 4: 0.3 % of those loci need more than +-6, none more than +-8), a miss is
+// a host round of about a millisecond (config 4's shard: 7 missed reads, 2 ms of an 8.2 ms call), and the wider window costs such
+// short motifs four more fork rows and no wider band class.
+constexpr int kWinMinLevel[kWinBuckets] = {3, 2, 2, 2, 2};
 // defaults of BandTune (strk_search.h): the band is laid around the table's middle +- kBandSpanW candidate sizes
 constexpr int kBandSpanW = 64, kBandSlackM8 = 0;
 // Scratch pool (int32 units): kLongWaves slots of kLongSlotInts for k_dp_long (one per resident wave; a slot
@@ -298,7 +303,12 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     // call's band pass is resident; k_hash / k_plan / k_replay need no LDS and fit NEXT to two band waves per SIMD (2 x 184 of
     // 512 VGPRs).  tools/grid_sweep2.sh, two calls in flight: 448 blocks 239 M reads/s, 480 -> 246 M, 496 -> 240 M, 512 -> 186 M
     // (round 2, three calls in flight and 219 VGPRs: 7/8 was the best).
-    const int sixteenths = g_calls_in_flight.load(std::memory_order_relaxed) > 1 ? 15 : 16;
+    // ... which pays when ONE kernel carries the call (BASELINE config 2: k_dp_band 1.15 ms, the others 0.13 ms; configs 3 and 5
+    // alike: k_dp_all / k_dp_band_wide alone).  Where k_dp_band AND k_dp_band_wide are both large — config 4's shard: 3.4 and 2.0
+    // ms — two calls' big kernels take turns on fifteen sixteenths of the chip each (measured with two calls in flight: 7.1 ms
+    // per call against 6.55 ms with whole grids; the other way round for configs 3 and 5: 8.9 against 7.7 ms, 3.5 against 2.65 ms):
+    // such a context takes the whole grid (hist_tail_heavy, from the previous call's cell counts).
+    const int sixteenths = (g_calls_in_flight.load(std::memory_order_relaxed) > 1 && !(c->hist_valid && c->hist_tail_heavy)) ? 15 : 16;
     // expected chunks of the sparsely used kernels, from the previous call of this context (same band mode), scaled
     // to this batch with 50 % head-room; without history every grid is the full resident one.  A grid that turns
     // out too small only makes that kernel slower: every wave pulls chunks until the queue is empty.
@@ -536,6 +546,10 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
         c->hist_exact_chunks = exact_chunks;
         c->hist_wide_chunks = wide_chunks;
         c->hist_long = c->h_counters[kCntClass0 + kLongClass];
+        {   // (cells, not event spans: with calls in flight a span includes the wait for the other call's kernels)
+            const unsigned long long* u = reinterpret_cast<const unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff);
+            c->hist_tail_heavy = u[kCellWide] > u[kCellBand] / 4 && u[kCellBand] > u[kCellWide] / 4;
+        }
     }
     {   // adaptive: noisy reads mostly fail the certificate and pay for both passes.  A context starts on probation
         // (the band sees the first kBandProbationReads reads of a call only, so a failure is cheap); a call with fewer

@@ -1,5 +1,5 @@
 // Opcode survey (round 3): which gfx950 VALU opcodes issue at the SIMD-32 rate (one wave64 instruction per ~2 cycles once
-// two or more waves share a SIMD) and which at ~4.2.  Same method as tools/valu_rate.hip (s_memtime inside the kernel,
+// two or more waves share a SIMD) and which at ~4.2.  Method (round 2's tools/valu_rate.hip, removed in round 4): s_memtime inside the kernel,
 // the clock the chip held from s_memrealtime, HIP events around the launch), four INDEPENDENT instructions per asm
 // statement, 2 and 4 waves per SIMD.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/valu_rate2 tools/valu_rate2.hip ; run on the GPU box:
