@@ -309,6 +309,21 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     // per call against 6.55 ms with whole grids; the other way round for configs 3 and 5: 8.9 against 7.7 ms, 3.5 against 2.65 ms):
     // such a context takes the whole grid (hist_tail_heavy, from the previous call's cell counts).
     const int sixteenths = (g_calls_in_flight.load(std::memory_order_relaxed) > 1 && !(c->hist_valid && c->hist_tail_heavy)) ? 15 : 16;
+    // tuning aid: STRKIT_AMD_GRID16="band,wide,exact" pins the sixteenths of the three persistent grids when calls overlap
+    static const std::array<int, 3> pin16 = [] {
+        std::array<int, 3> v{};
+        if (const char* e = getenv("STRKIT_AMD_GRID16")) {
+            for (int k = 0; k < 3 && *e; ++k) {
+                v[k] = atoi(e);
+                while (*e && *e != ',') ++e;
+                if (*e == ',') ++e;
+            }
+        }
+        return v;
+    }();
+    const bool overlap = g_calls_in_flight.load(std::memory_order_relaxed) > 1;
+    const int s16_band = (overlap && pin16[0] > 0) ? pin16[0] : sixteenths, s16_wide = (overlap && pin16[1] > 0) ? pin16[1] : sixteenths,
+              s16_exact = (overlap && pin16[2] > 0) ? pin16[2] : sixteenths;
     // expected chunks of the sparsely used kernels, from the previous call of this context (same band mode), scaled
     // to this batch with 50 % head-room; without history every grid is the full resident one.  A grid that turns
     // out too small only makes that kernel slower: every wave pulls chunks until the queue is empty.
@@ -324,7 +339,7 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     int band_blocks = 1;
     if (band) {
         // banded first pass: certified reads are done, the others are appended to the exact lists below
-        band_blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * sixteenths / 16, (a.list_stride + 3) / 4));
+        band_blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * s16_band / 16, (a.list_stride + 3) / 4));
         hipLaunchKernelGGL(k_dp_band, dim3(band_blocks), dim3(256), 0, st, a);
     }
     if (time_dp) (void)hipEventRecord(c->ev[kEvBand], st);
@@ -334,7 +349,8 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
             hipLaunchKernelGGL(k_sort_wide, dim3(64), dim3(256), 0, st, a, c->band_recs_w.as<int4>());
             aw.band_recs_w = c->band_recs_w.as<int4>();
         }
-        hipLaunchKernelGGL(k_dp_band_wide, dim3(predicted_blocks(c->hist_wide_chunks, band_blocks)), dim3(256), 0, st, aw);
+        const int wide_full = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * s16_wide / 16, (a.list_stride + 3) / 4));
+        hipLaunchKernelGGL(k_dp_band_wide, dim3(predicted_blocks(c->hist_wide_chunks, wide_full)), dim3(256), 0, st, aw);
     }
     if (time_dp) (void)hipEventRecord(c->ev[kEvWide], st);
     // first k_replay pass (strk_replay.h): as far as the certified band tables carry each locus, before the exact kernels
@@ -343,7 +359,7 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     if (!force_generic) {
         // persistent-style grid: every wave pulls chunks from the device-side queue until it is empty
         constexpr int kBlocksPerCU = std::max(1, std::min(8, (160 * 1024) / (4 * kWaveLdsBytes + kLdsSlack + 1024)));
-        const int full = std::max(1, std::min(tune > 0 ? tune : 256 * kBlocksPerCU * sixteenths / 16, (a.list_stride + 3) / 4));
+        const int full = std::max(1, std::min(tune > 0 ? tune : 256 * kBlocksPerCU * s16_exact / 16, (a.list_stride + 3) / 4));
         const int blocks = a.ref_mode ? full : predicted_blocks(c->hist_exact_chunks, full);
         if (a.ref_mode) hipLaunchKernelGGL(k_dp_ref, dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);

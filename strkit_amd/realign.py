@@ -136,13 +136,17 @@ def _gate(flank_size: int) -> float:
 
 
 def realign_reads(ref_seqs: Sequence[str], query_seqs: Sequence[str], left_flank_coords: Sequence[int], flank_size: int,
-                  context: _lib.Context | None = None) -> list[AlignedCoords | None]:
-    """``realign_read`` for many (reference window, wildcarded read) pairs in one device call.  A pair whose score does
-    not fit 16 bits (a window of more than 16 kb) is left un-realigned: the reference's 16-bit kernel would saturate there
-    and what it then compares with the threshold is not defined by the tree (``i16_saturation_flags``)."""
+                  context: _lib.Context | None = None, drop_i16_saturated: bool = False) -> list[AlignedCoords | None]:
+    """``realign_read`` for many (reference window, wildcarded read) pairs in one device call.
+
+    The reference compares whatever score ``sg_dx_trace_scan_16`` returns with its threshold and goes on (realign.py:56-72): it
+    has no saturation check, and a saturated 16-bit score is still far above the threshold.  The default therefore KEEPS a pair
+    whose score does not fit 16 bits (a window of more than 16 kb) with the exact 32-bit alignment computed here;
+    ``drop_i16_saturated=True`` leaves such pairs un-realigned instead (what a caller does who does not want results the
+    reference could only have produced from saturated cells; ``i16_saturation_flags`` tells which pairs those are)."""
     res = realign_pairs(ref_seqs, query_seqs, context=context)
     th = _gate(flank_size)
-    sat = i16_saturation_flags(ref_seqs, query_seqs, [sc for sc, _, _ in res]) if res else []
+    sat = i16_saturation_flags(ref_seqs, query_seqs, [sc for sc, _, _ in res]) if (res and drop_i16_saturated) else [0] * len(res)
     return [None if (sc < th or (f & _lib.STRK_I16_SCORE_SATURATES)) else get_aligned_pair_matches(cg, int(lfc), 0, swap=True)
             for (sc, _, cg), lfc, f in zip(res, left_flank_coords, sat)]
 
