@@ -45,6 +45,10 @@ N_SIMD = 256 * 4
 # cycles per 44 instructions at two waves per SIMD (the kernels' occupancy): 4.65 cycles per wave-instruction (independent
 # instructions of the same opcodes: 4.2-4.3, profiles/r03_valu_rate2.txt; one wave alone 5.7; only plain VOP2 adds reach 2.6).
 VALU_CYCLES_PER_INST = 4.65
+# ... per kernel: the two band kernels run that step; the exact kernel's stream (24-40 columns per lane, the adds independent of the
+# max chain) issues at the 4.3 of independent instructions (config 3: 4 077 M instructions in 7.4 ms at 2.3 GHz = 4.3 cycles each)
+VALU_CYCLES_BY_KERNEL = {"k_dp_band": 4.65, "k_dp_band_wide": 4.65}
+VALU_CYCLES_DEFAULT = 4.3
 DP_INSTS_PER_CELL_FLOOR = 2.25      # v_add_u32_sdwa + v_max3_i32 per cell + one v_perm_b32 per four cells
 PROFILE_TAG_PREV = "r03"
 PROFILE_TAG = "r04"                 # profiles/<tag>[_cfgN]_pmc_summary.json: the PMC passes of this same command (config N)
@@ -121,8 +125,9 @@ def cpu_baseline(cfg: int, sample_loci: int, pool, cores: int) -> dict:
             "reads_per_s_per_core": best["reads_per_s_per_core"], "gcups": best["gcups"], "scalar": out["scalar"], "simd": out.get("simd")}
 
 
-def pmc_file(cfg: int = 2) -> str | None:
-    """profiles/<tag>[_cfgN]_pmc_summary.json of this round, else the previous round's (named in the output)."""
+def pmc_file(cfg=2) -> str | None:
+    """profiles/<tag>[_cfgN]_pmc_summary.json of this round, else the previous round's (named in the output).  `cfg`: a
+    configuration number, or a key such as "5e" (config 5 at one GPU's share: its own profile, `r04_cfg5e_*`)."""
     for tag in (PROFILE_TAG, PROFILE_TAG_PREV):
         name = f"{tag}_pmc_summary.json" if cfg == 2 else f"{tag}_cfg{cfg}_pmc_summary.json"
         if os.path.exists(os.path.join(ROOT, "profiles", name)):
@@ -130,7 +135,7 @@ def pmc_file(cfg: int = 2) -> str | None:
     return None
 
 
-def pmc_summary(kernel: str, cfg: int = 2) -> dict | None:
+def pmc_summary(kernel: str, cfg=2) -> dict | None:
     """Per-launch PMC readings of `kernel` from the committed rocprofv3 passes of this same command on config `cfg`
     (profiles/README.md; separate --pmc passes, FETCH_SIZE / WRITE_SIZE in KiB)."""
     try:
@@ -153,26 +158,27 @@ def kernel_cells(acc: dict) -> dict:
             "k_dp_long": acc["long_cells"], "k_dp_generic": max(0, acc["cells"] - named)}
 
 
-def valu_block(kname: str, cfg: int, k_ms: float, cells_launch: float) -> dict | None:
+def valu_block(kname: str, cfg, k_ms: float, cells_launch: float) -> dict | None:
     """VALU-issue figures of ONE kernel: instruction count from the committed PMC pass of this command on config `cfg`, this
     run's un-overlapped duration and this run's cells OF THAT KERNEL."""
     pmc = pmc_summary(kname, cfg)
     if not pmc or "SQ_INSTS_VALU" not in pmc:
         return None
     clock_ghz = pmc.get("clock_ghz", 2.3)
-    floor_ms = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / N_SIMD / (clock_ghz * 1e9) * 1e3
+    cyc = VALU_CYCLES_BY_KERNEL.get(kname, VALU_CYCLES_DEFAULT)
+    floor_ms = pmc["SQ_INSTS_VALU"] * cyc / N_SIMD / (clock_ghz * 1e9) * 1e3
     return {"valu_from_profile": f"profiles/{pmc_file(cfg)}",
-            "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES_PER_INST,
+            "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": cyc,
             "valu_clock_ghz": clock_ghz, "floor_ms": floor_ms,
             "profile_kernel_ms": pmc.get("unoverlapped_avg_us", 0.0) / 1e3,
             "frac_valu": floor_ms / k_ms, "cells_per_launch": cells_launch,
             "insts_per_cell": pmc["SQ_INSTS_VALU"] * 64.0 / max(cells_launch, 1.0),
             "insts_per_cell_floor": DP_INSTS_PER_CELL_FLOOR,
-            "frac_of_cell_floor": (cells_launch / 64.0 * DP_INSTS_PER_CELL_FLOOR * VALU_CYCLES_PER_INST / N_SIMD
+            "frac_of_cell_floor": (cells_launch / 64.0 * DP_INSTS_PER_CELL_FLOOR * cyc / N_SIMD
                                    / (clock_ghz * 1e9) * 1e3) / k_ms}
 
 
-def roofline_block(cfg: int, acc_timed: dict, iso: dict | None, n_timed: int, plain: bool) -> dict:
+def roofline_block(cfg, acc_timed: dict, iso: dict | None, n_timed: int, plain: bool) -> dict:
     """`roofline` of the dominant kernel.  iso = per-kernel durations of one call at a time (un-overlapped), or None;
     acc_timed = the same sums over the timed region, where calls_in_flight launches share the device."""
     n = max(1, n_timed)
@@ -705,7 +711,7 @@ def main() -> None:
         el_c = time.perf_counter() - t_c
         v1c, ms1c, iso_c, _ = one_at_a_time(res_c, bl_c, 2, out_c[D])
         # (the one-at-a-time leg's last call ran batch 1 into out_c[D])
-        roof_c = roofline_block(c, ac_c, iso_c, ac_c["n"], True)
+        roof_c = roofline_block("5e" if name == "cfg5" else c, ac_c, iso_c, ac_c["n"], True)
         dp_ms_c = sum(iso_c[k] for k, _ in DP_KERNELS)
         configs_out[name] = {
             "workload": SUB_CONFIGS[name][2], "loci_per_step": bl_c[0].n_loci, "reads_per_step": bl_c[0].n_reads,

@@ -394,6 +394,40 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// One read (strk_repeat_count, the scalar drop-in of repeats.py:47-70): the plan of its short launch chain.  Zeroes the counters,
+// gives read 0 its window by k_plan's rule, its class and its list entry; k_dp_all (one block) then scores the window and
+// searches it from the start count (the "speculative" search for start == est_cn IS the call's search: no feedback here).
+// A read no fast class takes, or whose search leaves the window, keeps spec[0] = miss and goes the general way.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_scalar_plan(KArgs a, int n_counter_ints) {
+    for (int i = threadIdx.x; i < n_counter_ints; i += 64) a.counters[i] = 0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int nfl = a.nfl[0], ntr = a.ntr[0], nfr = a.nfr[0], m = a.motif_off[1] - a.motif_off[0];
+    a.read_locus[0] = 0;
+    a.tab_off[0] = 0;
+    a.spec[0] = make_int4(0, 0, 0, kSpecMiss);
+    a.win_lo[0] = 0;
+    a.win_n[0] = 0;
+    if (m < 1 || nfl < 0 || ntr < 0 || nfr < 0) { a.counters[kCntError] = kErrBadInput; return; }
+    const long long est = a.est_cn[0];
+    const long long w = min((long long)a.window + min(max(est, 0ll) >> 7, 7ll), (long long)(a.table_stride - 1) / 2);
+    long long w_lo = est - w, w_hi = est + w;
+    if (w_lo < 0) w_lo = 0;
+    if (w_hi < w_lo) w_hi = w_lo;
+    if (w_hi - w_lo + 1 > a.table_stride) w_hi = w_lo + a.table_stride - 1;
+    const int lo = (int)w_lo, n = (int)(w_hi - w_lo + 1);
+    a.win_lo[0] = lo;
+    a.win_n[0] = n;
+    const int c = classify(nfl, ntr, nfr, m, lo, n, 0, 0);
+    if (c < kNumClasses) {
+        a.cls_list[(size_t)c * a.list_stride * 2] = 0;
+        a.cls_list[(size_t)c * a.list_stride * 2 + 1] = 0;
+        a.counters[kCntClass0 + c] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Longest first: the items of the four wide band classes, re-listed by descending prefix rows (counting sort on rows / 64 from
 // k_plan's census; order inside a bucket is whatever the cursors hand out — results do not depend on it).  A wave of
 // k_dp_band_wide works for milliseconds on one 12 000-row read: the queue must not hold such a chunk back until other waves

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import ALPHA_WC, oracle_count, random_locus
+from helpers import ALPHA_ACGT, ALPHA_IUPAC, ALPHA_WC, oracle_count, rand_seq, random_locus
 from strkit_amd.synth import LocusBatch, make_config
 
 pytestmark = pytest.mark.gpu
@@ -333,3 +333,47 @@ def test_pin_cases_fixture(gpu_ctx):
                 assert json.loads(json.dumps(res)) == ref["expected"][k], (l["motif"], respect)
                 k += 1
 
+
+
+def test_scalar_fast_path_equals_the_oracle_on_every_shape(gpu_ctx):
+    """strk_repeat_count's short launch chain (one upload, k_scalar_plan + k_dp_all on one block, one download) and the
+    general path it falls back to — long windows, empty flanks, IUPAC-rich reads, starts far from the tract, start 0, other
+    search parameters — against the oracle; and what one call costs."""
+    import time
+    import oracle
+    from strkit_amd.repeat_count_params import RepeatCountParams, default_read_rc_params
+    from strkit_amd.repeats import get_repeat_count
+    rng = np.random.default_rng(77)
+    rc = default_read_rc_params()
+    cases = []
+    for it in range(60):
+        alpha = (ALPHA_WC, ALPHA_ACGT, ALPHA_IUPAC)[it % 3]
+        motif, reads = random_locus(rng, 1, motif_len=(1, 12), cn=(0, 60), flank=(1, 90), alpha=alpha)
+        fl, tr, fr = reads[0]
+        shift = int(rng.integers(-3, 4)) if it % 4 else int(rng.integers(-30, 31))
+        cases.append((max(0, round(len(tr) / len(motif)) + shift), tr, fl, fr, motif, rc))
+    fl, fr = rand_seq(rng, 70), rand_seq(rng, 70)
+    cases += [(0, "", fl, fr, "CAG", rc), (3, "CAGCAGCAG", "", fr, "CAG", rc), (3, "CAGCAGCAG", fl, "", "CAG", rc),
+              (400, "CAG" * 400, fl, fr, "CAG", rc),                                  # 1 340 bases: the widest fast class
+              (700, "AT" * 700 + "A", fl, fr, "AT", rc),                                # beyond it: the general path (k_dp_long)
+              (12, "CAG" * 12, fl, fr, "CAG", RepeatCountParams("repalign", 5, 3, 1)),  # max_iters cut-off
+              (12, "CAG" * 20, fl, fr, "CAG", RepeatCountParams("repalign", 50, 5, 2)),
+              (2, "CAG" * 25, fl, fr, "CAG", rc)]                                       # a chase that leaves the window: general path
+    for start, tr, a, c, motif, p in cases:
+        get_repeat_count.cache_clear()
+        try:
+            exp = oracle.repeat_count(start, tr, a, c, motif, p.max_iters, p.initial_local_search_range, p.initial_step_size)
+        except ValueError:
+            with pytest.raises(ValueError):
+                get_repeat_count(start, tr, a, c, motif, p)
+            continue
+        assert get_repeat_count(start, tr, a, c, motif, p) == exp, (start, len(tr), len(a), len(c), motif)
+    # latency of the drop-in (lru_cache bypassed): a 30-copy CAG tract with 70-base flanks
+    tr = "CAG" * 30
+    t0 = time.perf_counter()
+    n = 300
+    for k in range(n):
+        get_repeat_count.__wrapped__(30 + (k % 3) - 1, tr, fl, fr, "CAG", rc)
+    us = (time.perf_counter() - t0) / n * 1e6
+    print(f"\n[scalar drop-in] {us:.1f} us per get_repeat_count call (round 3: about 100 us through the batched path)")
+    assert us < 500
