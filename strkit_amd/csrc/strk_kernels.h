@@ -419,8 +419,18 @@ __global__ void __launch_bounds__(64) k_scalar_plan(KArgs a, int n_counter_ints)
     const int lo = (int)w_lo, n = (int)(w_hi - w_lo + 1);
     a.win_lo[0] = lo;
     a.win_n[0] = n;
-    const int c = classify(nfl, ntr, nfr, m, lo, n, 0, 0);
+    int c = classify(nfl, ntr, nfr, m, lo, n, 0, 0);
     if (c < kNumClasses) {
+        // one read alone: latency, not throughput — the class whose wave finishes first (more lanes, fewer columns per lane: a step
+        // costs about 9/4 CL + 12 instructions and a pass has rows + G - 1 of them), not the one with the fewest lanes
+        const long long ndb = (long long)nfl + ntr + nfr, rows = (long long)nfl + (long long)(lo + n - 1) * m;
+        long long best = -1;
+        for (int k = c; k < kNumClasses; ++k) {
+            const int cap = class_cap(k);
+            if (ndb + 1 > cap || rows > cap + kRowSlack) continue;
+            const long long cost = (rows + nfr + 2 * class_G(k)) * (9 * class_CL(k) / 4 + 12);
+            if (best < 0 || cost < best) { best = cost; c = k; }
+        }
         a.cls_list[(size_t)c * a.list_stride * 2] = 0;
         a.cls_list[(size_t)c * a.list_stride * 2 + 1] = 0;
         a.counters[kCntClass0 + c] = 1;
