@@ -16,3 +16,13 @@ def pytest_configure(config):
 def gpu_ctx():
     from strkit_amd import _lib
     return _lib.default_context(0)
+
+
+@pytest.fixture
+def fresh_ctx():
+    """A context of its own: a shared one carries what earlier batches taught it (a band cool-down after noisy reads, grid
+    history), which a test that asserts on the band's statistics must not depend on."""
+    from strkit_amd import _lib
+    ctx = _lib.Context(0)
+    yield ctx
+    ctx.close()
