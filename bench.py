@@ -721,6 +721,8 @@ def main() -> None:
             "band_fallback_per_step": ac_c["band_fb"] / ac_c["n"], "window_miss_reads_per_step": ac_c["misses"] / ac_c["n"],
             "generic_kernel_items_per_step": ac_c["fallback"] / ac_c["n"], "dedup_reads_per_step": ac_c["dedup"] / ac_c["n"],
             "gcups": iso_c["cells"] / max(dp_ms_c, 1e-9) / 1e6, "roofline": roof_c,
+            "overlapped_ms": {**{k: ac_c[f] / ac_c["n"] for k, f in DP_KERNELS}, "head": ac_c["head_ms"] / ac_c["n"],
+                              "replay": ac_c["replay_ms"] / ac_c["n"], "device": ac_c["all_ms"] / ac_c["n"]},
             "parity_check": parity_check(bl_c[1], out_c[D, 1:5].cpu().numpy()),
         }
         del res_c, out_c
@@ -754,6 +756,9 @@ def main() -> None:
                      "unit": "G cell updates/s: cells the DP kernels executed per call / the summed un-overlapped durations of all five "
                              "DP kernels (one call at a time)"},
             "device_ms_per_step": acc["all_ms"] / n,
+            # event spans inside the timed region, where calls_in_flight calls share the device (a span includes the wait for
+            # the other call's kernels): where a call's time goes when calls overlap
+            "overlapped_ms": {**{k: acc[f] / n for k, f in DP_KERNELS}, "head": acc["head_ms"] / n, "replay": acc["replay_ms"] / n},
             "band_reads_per_step": acc["band"] / n, "band_fallback_per_step": acc["band_fb"] / n, "band": not a.no_band,
             "window_miss_reads_per_step": acc["misses"] / n, "generic_kernel_items_per_step": acc["fallback"] / n,
             "dedup_reads_per_step": acc["dedup"] / n, "dedupe": not a.no_dedupe,

@@ -63,6 +63,12 @@ std::atomic<int> g_calls_in_flight{0};
 std::atomic<int> g_win_level[strk::kWinBuckets] = {{kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}};
 std::atomic<int> g_win_quiet[strk::kWinBuckets] = {{0}, {0}, {0}, {0}, {0}};
 
+// The band pass most recently enqueued by any context of this process (its kEvBand event): in whole-grid mode the next call's
+// band pass waits for it (enqueue_scoring), so that two calls in flight run half a period apart whatever their submit times.
+std::mutex g_band_chain_mu;
+hipEvent_t g_band_chain_ev = nullptr;
+int g_band_chain_dev = -1;
+
 // CPUs this process may run on (a container's share, not the machine's core count)
 int host_cpus() {
     cpu_set_t set;
@@ -311,7 +317,9 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     // ms — two calls' big kernels take turns on fifteen sixteenths of the chip each (measured with two calls in flight: 7.1 ms
     // per call against 6.55 ms with whole grids; the other way round for configs 3 and 5: 8.9 against 7.7 ms, 3.5 against 2.65 ms):
     // such a context takes the whole grid (hist_tail_heavy, from the previous call's cell counts).
-    const int sixteenths = (g_calls_in_flight.load(std::memory_order_relaxed) > 1 && !(c->hist_valid && c->hist_tail_heavy)) ? 15 : 16;
+    static const int force_heavy = getenv("STRKIT_AMD_FORCE_HEAVY") ? atoi(getenv("STRKIT_AMD_FORCE_HEAVY")) : -1;   // tuning aid: 1 / 0 pins the rule
+    const bool heavy = force_heavy >= 0 ? force_heavy != 0 : (c->hist_valid && c->hist_tail_heavy);
+    const int sixteenths = (g_calls_in_flight.load(std::memory_order_relaxed) > 1 && !heavy) ? 15 : 16;
     // tuning aid: STRKIT_AMD_GRID16="band,wide,exact" pins the sixteenths of the three persistent grids when calls overlap
     static const std::array<int, 3> pin16 = [] {
         std::array<int, 3> v{};
@@ -338,14 +346,34 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
         return std::max(1, std::min(full, blocks));
     };
     if (time_dp) (void)hipEventRecord(c->ev[kEvHead], st);
+    static const bool grid_dbg = getenv("STRKIT_AMD_GRID_DEBUG") != nullptr;
+    if (grid_dbg && mode == 0)
+        fprintf(stderr, "[strk grid] ctx %p reads %d in flight %d hist %d heavy %d -> sixteenths %d (wide chunks %d, exact chunks %d)\n", (void*)c, a.n_reads,
+                g_calls_in_flight.load(), (int)c->hist_valid, (int)c->hist_tail_heavy, sixteenths, c->hist_wide_chunks, c->hist_exact_chunks);
     const bool band = a.band_mode && mode == 0 && !force_generic;
     int band_blocks = 1;
+    if (band && time_dp) {
+        // Whole-grid mode (two large kernels per call): which way two calls in flight share the device is decided by their phase.
+        // Half a period apart, one call's k_dp_band_wide and tails run inside the other's k_dp_band (config 4's shard: 5.8 ms per
+        // call); in phase, the two band passes co-run at half speed, then the two wide passes, and the tails of both are left with
+        // nothing to hide in (6.9 ms).  Both patterns sustain themselves; two submits in a row on an idle device start the second
+        // one.  So a band pass waits for the band pass enqueued before it, whichever context that was: the calls fall half a
+        // period apart by themselves.
+        std::lock_guard<std::mutex> lk(g_band_chain_mu);
+        if (sixteenths == 16 && overlap && g_band_chain_ev && g_band_chain_ev != c->ev[kEvBand] && g_band_chain_dev == c->device)
+            (void)hipStreamWaitEvent(st, g_band_chain_ev, 0);
+    }
     if (band) {
         // banded first pass: certified reads are done, the others are appended to the exact lists below
         band_blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * s16_band / 16, (a.list_stride + 3) / 4));
         hipLaunchKernelGGL(k_dp_band, dim3(band_blocks), dim3(256), 0, st, a);
     }
     if (time_dp) (void)hipEventRecord(c->ev[kEvBand], st);
+    if (band && time_dp) {
+        std::lock_guard<std::mutex> lk(g_band_chain_mu);
+        g_band_chain_ev = c->ev[kEvBand];
+        g_band_chain_dev = c->device;
+    }
     if (band) {   // long windows
         KArgs aw = a;
         if (sort_wide) {
@@ -872,6 +900,10 @@ void strk_destroy(strk_ctx* c) {
                       &c->out_start, &c->rl_s1, &c->rl_s2, &c->rl_pairs, &c->rl_trace, &c->rl_edge, &c->rl_out, &c->rl_cigar,
                       &c->rl_queue, &c->band_recs_w, &c->sc_dev};
     for (DevBuf* b : bufs) b->release();
+    {
+        std::lock_guard<std::mutex> lk(g_band_chain_mu);
+        if (g_band_chain_ev == c->ev[kEvBand]) g_band_chain_ev = nullptr;
+    }
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->sc_host) (void)hipHostFree(c->sc_host);
     if (c->sc_out) (void)hipHostFree(c->sc_out);
