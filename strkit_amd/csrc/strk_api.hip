@@ -333,6 +333,9 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
         return v;
     }();
     const bool overlap = g_calls_in_flight.load(std::memory_order_relaxed) > 1;
+    // tuning aid: block slots a whole grid of an overlapping call leaves free (for the other call's small LDS-holding kernels)
+    static const int spare_env = getenv("STRKIT_AMD_GRID_SPARE") ? atoi(getenv("STRKIT_AMD_GRID_SPARE")) : 0;
+    const int spare = overlap ? std::max(0, spare_env) : 0;
     const int s16_band = (overlap && pin16[0] > 0) ? pin16[0] : sixteenths, s16_wide = (overlap && pin16[1] > 0) ? pin16[1] : sixteenths,
               s16_exact = (overlap && pin16[2] > 0) ? pin16[2] : sixteenths;
     // expected chunks of the sparsely used kernels, from the previous call of this context (same band mode), scaled
@@ -365,7 +368,7 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     }
     if (band) {
         // banded first pass: certified reads are done, the others are appended to the exact lists below
-        band_blocks = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * s16_band / 16, (a.list_stride + 3) / 4));
+        band_blocks = std::max(1, std::min(tune > 0 ? tune : std::max(1, 256 * kBandBlocksPerCU * s16_band / 16 - (s16_band == 16 ? spare : 0)), (a.list_stride + 3) / 4));
         hipLaunchKernelGGL(k_dp_band, dim3(band_blocks), dim3(256), 0, st, a);
     }
     if (time_dp) (void)hipEventRecord(c->ev[kEvBand], st);
@@ -380,7 +383,7 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
             hipLaunchKernelGGL(k_sort_wide, dim3(64), dim3(256), 0, st, a, c->band_recs_w.as<int4>());
             aw.band_recs_w = c->band_recs_w.as<int4>();
         }
-        const int wide_full = std::max(1, std::min(tune > 0 ? tune : 256 * kBandBlocksPerCU * s16_wide / 16, (a.list_stride + 3) / 4));
+        const int wide_full = std::max(1, std::min(tune > 0 ? tune : std::max(1, 256 * kBandBlocksPerCU * s16_wide / 16 - (s16_wide == 16 ? spare : 0)), (a.list_stride + 3) / 4));
         hipLaunchKernelGGL(k_dp_band_wide, dim3(predicted_blocks(c->hist_wide_chunks, wide_full)), dim3(256), 0, st, aw);
     }
     if (time_dp) (void)hipEventRecord(c->ev[kEvWide], st);
