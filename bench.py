@@ -691,7 +691,9 @@ def main() -> None:
             _lib.check(L.strk_count_loci_device(ctxs[i % D].handle, C.byref(res_c[i % 2][1]), C.byref(p), out_c[0, 1].data_ptr(),
                                                 out_c[0, 2].data_ptr(), out_c[0, 3].data_ptr(), out_c[0, 4].data_ptr(),
                                                 C.c_void_p(streams[i % D].cuda_stream), C.byref(st)))
-        k_steps = 12                           # (two calls in flight: the first and the last step of the timed region overlap with nothing)
+        # (two calls in flight: the first and the last step of the timed region overlap with nothing — enough steps that this
+        # ramp is a few per cent: about 100-200 ms of device time per configuration)
+        k_steps = {"cfg3": 16, "cfg4": 20, "cfg5": 32, "cfg5_all": 8}.get(name, 12)
         ac_c = new_acc()
         fence()
         t_c = time.perf_counter()
