@@ -142,7 +142,8 @@ struct strk_ctx {
     // first k_replay pass | after k_dp_all / k_dp_ref | after k_dp_long | after k_dp_generic | end (after k_replay and the
     // counters' copy)
     hipEvent_t ev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_ints = 0;
+    size_t scratch_ints = 0;        // = kLongWaves * long_slot_ints + generic_ints
+    size_t long_slot_ints = 0, generic_ints = 0;   // (set where the constants are known: strk_create)
     int band_cooldown = 0;   // > 0: the band kernel is switched off for that many calls (too many certificates failed)
     int band_penalty = 32;   // length of the next cool-down (doubles while retries keep failing)
     bool band_probation = true;   // the band has not proved itself on this context's data yet: only a sample of the reads takes it
@@ -158,6 +159,8 @@ struct strk_ctx {
     bool pending = false;
     strk_batch p_batch;
     strk_params p_params;
+    strk_params p_params_in;       // as the caller gave them (a call that is run again goes through check_params again)
+    int scratch_reruns = 0;        // the submitted call is a re-run of one that asked for more scratch than there was (grow_scratch)
     strk::KArgs p_args;
     strk::ReplayArgs p_replay;
     hipStream_t p_stream = nullptr;
@@ -195,7 +198,11 @@ constexpr int kBandSpanW = 64, kBandSlackM8 = 0;
 constexpr int kBandBlocksPerCU = std::max(1, std::min(8, (160 * 1024) / (4 * kBandWaveLds + kLdsSlack + 1024)));
 constexpr int kLongBlocks = 512, kLongWaves = kLongBlocks * 4;   // 2 waves per SIMD
 constexpr size_t kLongSlotInts = (size_t)48 << 10;
-constexpr size_t kScratchInts = kLongWaves * kLongSlotInts + ((size_t)16 << 20);
+constexpr size_t kGenericPoolInts = (size_t)16 << 20;
+// what the two parts may grow to when a call asks for more (grow_scratch): a slot for the longest window classify() sends to
+// k_dp_long (64 column tiles + two boundary columns of 2^20 rows: 18 GB for the 2 048 slots), 32 GiB of generic-kernel rows
+constexpr size_t kLongSlotMaxInts = (size_t)kLongTile * kLongMaxTiles + 2 * (((size_t)1 << 20) + 256);
+constexpr unsigned long long kGenericPoolMaxInts = 8ull << 30;
 // device layout of the `counters` buffer: int32[kCntTotal] | pad | u64 cells | u64 scratch_used
 constexpr size_t kCellsOff = 64 * sizeof(int32_t);
 constexpr size_t kCountersBytes = kCellsOff + 10 * sizeof(unsigned long long);   // cells, scratch_used, band / exact / wide-band / long-kernel bytes, cells per kernel (kCell*)
@@ -238,8 +245,8 @@ int ensure_workspace(strk_ctx* c, int n_reads, int n_loci, size_t table_ints, si
     if ((rc = c->rep.ensure(nr * 4))) return rc;
     if ((rc = c->exact.ensure(nr))) return rc;
     if (!c->scratch.p) {
-        if ((rc = c->scratch.ensure(kScratchInts * 4))) return rc;
-        c->scratch_ints = kScratchInts;
+        if ((rc = c->scratch.ensure(((size_t)kLongWaves * c->long_slot_ints + c->generic_ints) * 4))) return rc;
+        c->scratch_ints = (size_t)kLongWaves * c->long_slot_ints + c->generic_ints;
     }
     return 0;
 }
@@ -265,7 +272,7 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
     a.scratch_used = a.cells + 1;
     a.scratch = c->scratch.as<int32_t>();
     a.scratch_cap = (long long)c->scratch_ints;
-    a.long_slot = (long long)kLongSlotInts;
+    a.long_slot = (long long)c->long_slot_ints;
     a.long_waves = kLongWaves;
     a.list_stride = list_stride;
     static const int dbg = getenv("STRKIT_AMD_DBG") ? atoi(getenv("STRKIT_AMD_DBG")) : 0;
@@ -403,13 +410,42 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
         hipLaunchKernelGGL(k_dp_long, dim3(mode == 0 ? predicted_blocks(c->hist_long, kLongBlocks) : std::max(1, std::min(kLongBlocks, a.list_stride))),
                            dim3(256), 0, st, a);
     if (time_dp) (void)hipEventRecord(c->ev[kEvLong], st);
-    hipLaunchKernelGGL(k_dp_generic, dim3(256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dp_generic, dim3(1024), dim3(256), 0, st, a);   // one wave per (item, candidate): 4 096 waves
     if (time_dp) (void)hipEventRecord(c->ev[kEvGeneric], st);
+}
+
+// A call asked for more scratch than the context holds — rows of the generic kernel (its pool starts at 64 MiB), or a slot of
+// k_dp_long for a window longer than ~20 000 candidate rows (a slot starts at 192 KiB): make that part as large as what was
+// asked for (the device counted every request, served or not) and say that the call is to be run again.  Reads the generic
+// kernel takes are rare (an empty flank, more than eight distinct symbols in a window, a motif longer than kMotifMax), and so
+// are start counts dozens of times the tract's size, but a batch of a few hundred loci made of either must not fail for it.
+bool grow_scratch(strk_ctx* c) {
+    const int bits = c->h_counters[kCntError];
+    if (!(bits & (kErrScratch | kErrLongSlot))) return false;
+    size_t slot = c->long_slot_ints, gen = c->generic_ints;
+    if (bits & kErrLongSlot) {
+        const size_t need = (size_t)std::max(0, c->h_counters[kCntLongNeed]);
+        if (need <= slot || need > kLongSlotMaxInts) return false;
+        slot = (need + need / 8 + 1023) & ~(size_t)1023;
+    }
+    if (bits & kErrScratch) {
+        const unsigned long long used = reinterpret_cast<const unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + kCellsOff)[1];
+        if (used <= gen || used > kGenericPoolMaxInts) return false;
+        gen = (size_t)used + (1u << 16);
+    }
+    const size_t want = (size_t)kLongWaves * slot + gen;
+    if (c->scratch.ensure(want * 4, false)) return false;
+    c->long_slot_ints = slot;
+    c->generic_ints = gen;
+    c->scratch_ints = want;
+    return true;
 }
 
 int check_error_bits(int bits) {
     if (bits & kErrBadInput) return fail(STRK_E_INVALID, "batch holds an empty motif or a negative length");
-    if (bits & kErrScratch) return fail(STRK_E_NOMEM, "generic-kernel scratch or item list exhausted (inputs too large for one call)");
+    if (bits & kErrScratch) return fail(STRK_E_NOMEM, "generic-kernel scratch exhausted (inputs too large for one call)");
+    if (bits & kErrList) return fail(STRK_E_NOMEM, "a kernel's item list is full (more items than the call sized its lists for)");
+    if (bits & kErrLongSlot) return fail(STRK_E_NOMEM, "a window is too long for the long-read kernel's scratch slot (|db| + 2 x candidate rows > %zu)", kLongSlotMaxInts);
     if (bits & kErrEmpty) return fail(STRK_E_EMPTY, "max() arg is an empty sequence: no candidate size could be scored for some read");
     return 0;
 }
@@ -450,6 +486,7 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     }
     c->p_batch = *b;
     c->p_params = p;
+    c->p_params_in = *params;
     c->p_stream = st;
     if (b->n_reads == 0 || b->n_loci == 0) {
         c->pending = true;
@@ -507,6 +544,16 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(c->ev[kEvEnd]));
     HIP_TRY(hipGetLastError());
+    if (c->scratch_reruns < 3 && grow_scratch(c)) {   // the same call once more, with the scratch it asked for
+        const strk_batch again = c->p_batch;
+        const strk_params pin = c->p_params_in;
+        const ReplayArgs rp = c->p_replay;
+        ++c->scratch_reruns;
+        int rc = submit_device(c, &again, &pin, rp.out_cn, rp.out_score, rp.out_n, rp.out_start, c->p_stream);
+        if (!rc) rc = finish_device(c, stats);
+        --c->scratch_reruns;
+        return rc;
+    }
     if (stats) {
         auto span = [&](int from, int to) {
             float ms = 0.f;
@@ -782,13 +829,22 @@ int score_table_impl(strk_ctx* ctx, const strk_batch* batch, const int32_t* lo, 
     HIP_TRY(hipMemcpyAsync(a.win_lo, lo, nr * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(a.win_n, n, nr * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(a.tab_off, off_dev.data(), nr * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, kCountersBytes, st));
-    HIP_TRY(hipEventRecord(ctx->ev[kEvStart], st));
-    enqueue_scoring(ctx, a, 1, nullptr, batch->n_reads, force_generic, st, true);
-    HIP_TRY(hipEventRecord(ctx->ev[kEvEnd], st));
-    HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipGetLastError());
+    for (int attempt = 0;; ++attempt) {
+        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, kCountersBytes, st));
+        HIP_TRY(hipEventRecord(ctx->ev[kEvStart], st));
+        enqueue_scoring(ctx, a, 1, nullptr, batch->n_reads, force_generic, st, true);
+        HIP_TRY(hipEventRecord(ctx->ev[kEvEnd], st));
+        HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->counters.p, kCountersBytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
+        if (attempt < 3 && grow_scratch(ctx)) {   // once more, with the scratch the call asked for
+            a.scratch = ctx->scratch.as<int32_t>();
+            a.scratch_cap = (long long)ctx->scratch_ints;
+            a.long_slot = (long long)ctx->long_slot_ints;
+            continue;
+        }
+        break;
+    }
     if ((rc = check_error_bits(ctx->h_counters[kCntError]))) return rc;
     if (tab) {
         if (!ref_mode) {
@@ -876,6 +932,8 @@ int strk_init(int device, strk_ctx** out) {
         return fail(STRK_E_NODEV, "device %d is %s; this library holds gfx950 code objects only", device, prop.gcnArchName);
     strk_ctx* c = new strk_ctx();
     c->device = device;
+    c->long_slot_ints = kLongSlotInts;
+    c->generic_ints = kGenericPoolInts;
     strk::ScoreTables t;
     strk::build_score_tables(&t);
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(strk::c_mat), t.mat, sizeof t.mat);

@@ -529,7 +529,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
                 gl[2 * idx] = r;
                 gl[2 * idx + 1] = 0;
             } else {
-                atomicOr(&a.counters[kCntError], kErrScratch);
+                atomicOr(&a.counters[kCntError], kErrList);
             }
             a.exact[r] = 1;
             atomicAdd(&a.counters[kCntBandFallback], 1);

@@ -397,7 +397,7 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
                 gl[2 * idx] = r;
                 gl[2 * idx + 1] = k0;
             } else {
-                atomicOr(&counters[kCntError], kErrScratch);
+                atomicOr(&counters[kCntError], kErrList);
             }
         }
         act = false;

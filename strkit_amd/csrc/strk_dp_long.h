@@ -72,7 +72,10 @@ __global__ void __launch_bounds__(256) k_dp_long(KArgs a) {
         // ---- global scratch (this wave's own slot): backward row of all tiles + two boundary columns
         const long long need = (long long)NT * TW + 2ll * colLen;
         if (need > a.long_slot) {
-            if (first) atomicOr(&a.counters[kCntError], kErrScratch);
+            if (first) {   // the host makes the slots as large as the largest request and runs the call again (grow_scratch)
+                atomicOr(&a.counters[kCntError], kErrLongSlot);
+                atomicMax(&a.counters[kCntLongNeed], (int)min(need, 0x7fffffffll));
+            }
             continue;
         }
         const long long at = (long long)(blockIdx.x * 4 + (threadIdx.x >> 6)) * a.long_slot;
@@ -107,7 +110,7 @@ __global__ void __launch_bounds__(256) k_dp_long(KArgs a) {
                     gl[2 * idx] = r;
                     gl[2 * idx + 1] = k0;
                 } else {
-                    atomicOr(&a.counters[kCntError], kErrScratch);
+                    atomicOr(&a.counters[kCntError], kErrList);
                 }
             }
             continue;
@@ -308,18 +311,28 @@ __global__ void __launch_bounds__(256) k_dp_long(KArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Generic kernel: one thread per (item, candidate); plain row-by-row DP with the H row in global
-// scratch.  Takes every shape the fast classes do not (empty flanks, > 8 distinct symbols in the
-// read window, windows longer than the largest class).  Correctness path, not a fast path.
+// Generic kernel: one WAVE per (item, candidate); plain row-by-row DP with the H row in global scratch, lane l of the
+// wave owning the columns 1 + l, 65 + l, ... .  Takes every shape the fast classes do not (empty flanks, > 8 distinct
+// symbols in the read window, motifs longer than kMotifMax).  Correctness path, not a fast path — but a batch of such reads
+// with starts far from their tracts' sizes ran for minutes with one THREAD per candidate (tools/fuzz_parity.py), hence the
+// wave: within a row, H(j) = max(h'(j), H(j-1) - g) with h'(j) = max(diag + w, up - g) is a running maximum of
+// U(j) = H(j) + g j = max(h'(j) + g j, U(j-1)) — 64 columns at a time by an inclusive prefix maximum over the lanes, the carry
+// U of the block before handed on.  Every scratch word is read and written by one lane only (diag comes by shuffle).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_dp_generic(KArgs a) {
+__global__ void __launch_bounds__(256) k_dp_generic(KArgs a) {
     const int count = min(a.counters[kCntClass0 + kGenericClass], a.list_stride);
     if (count <= 0) return;
     const int32_t* list = a.cls_list + (size_t)kGenericClass * a.list_stride * 2;
     const bool dbBeg = a.end_flags & 1, dbEnd = a.end_flags & 2, cBeg = a.end_flags & 4, cEnd = a.end_flags & 8;
     constexpr int g = kGap;
+    const int lane = threadIdx.x & 63;
     const long long total = (long long)count * kTableMax;
-    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    // a wave keeps the row it has and takes a new one only when the next window is longer: the pool then holds at most one
+    // row (of the longest window) per wave however many items a call brings, and the host grows it when even that does not
+    // fit (scratch_used counts what was ASKED for, served or not: strk_api.hip, grow_scratch)
+    unsigned long long myAt = 0, myCap = 0;
+    for (long long w = wave0; w < total; w += n_waves) {
         const int it = (int)(w / kTableMax), k = (int)(w % kTableMax);
         const int r = list[2 * it], k0 = list[2 * it + 1];
         const int n = min(kTableMax, a.win_n[r] - k0);
@@ -335,46 +348,83 @@ __global__ void k_dp_generic(KArgs a) {
         const long long ncand = (long long)nfl + (long long)i * m + ncfr;
         int32_t* out = a.ref_mode ? a.table + a.tab_off[r] + 2 * (k0 + k) : a.table + a.tab_off[r] + k0 + k;
         if (ndb <= 0 || ncand <= 0) {
-            out[0] = 0;
-            if (a.ref_mode) out[1] = -1;
+            if (lane == 0) {
+                out[0] = 0;
+                if (a.ref_mode) out[1] = -1;
+            }
             continue;
         }
         const unsigned long long need = (unsigned long long)ndb + 1;
-        const unsigned long long at = (unsigned long long)a.long_slot * a.long_waves + atomicAdd(a.scratch_used, need);
-        if (at + need > (unsigned long long)a.scratch_cap) {
-            atomicOr(&a.counters[kCntError], kErrScratch);
-            out[0] = 0;
-            if (a.ref_mode) out[1] = -1;
+        if (need > myCap) {
+            unsigned long long at = 0;
+            if (lane == 0) at = atomicAdd(a.scratch_used, need);
+            at = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at & 0xffffffffull)) |
+                 ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32);
+            myAt = (unsigned long long)a.long_slot * a.long_waves + at;
+            myCap = myAt + need > (unsigned long long)a.scratch_cap ? 0 : need;
+        }
+        if (need > myCap) {
+            if (lane == 0) {
+                atomicOr(&a.counters[kCntError], kErrScratch);
+                out[0] = 0;
+                if (a.ref_mode) out[1] = -1;
+            }
             continue;
         }
-        int32_t* Hrow = a.scratch + at;
-        Hrow[0] = 0;
-        for (int j = 1; j <= ndb; ++j) Hrow[j] = dbBeg ? 0 : -g * j;
+        int32_t* Hrow = a.scratch + myAt;          // Hrow[j], j = 1..ndb (column 0 lives in registers)
+        const int n_blocks = (ndb + 63) >> 6;
+        for (int j = 1 + lane; j <= ndb; j += 64) Hrow[j] = dbBeg ? 0 : -g * j;
         int lastcol = kNegInf;
+        int h0_prev = 0;                           // H(rr - 1, 0)
         for (long long rr = 1; rr <= ncand; ++rr) {
             const long long p = rr - 1;
             const uint8_t ch = p < nfl ? db[p] : (p < nfl + (long long)i * m ? motif[(p - nfl) % m] : db[nfl + ntr + (p - nfl - (long long)i * m)]);
             const int8_t* wrow = c_mat[c_enc[ch]];
-            int diag = Hrow[0];
-            int left = cBeg ? 0 : (int)(-g * rr);
-            Hrow[0] = left;
-            for (int j = 1; j <= ndb; ++j) {
-                const int up = Hrow[j];
-                int h = diag + wrow[c_enc[db[j - 1]]];
-                h = max(h, max(up, left) - g);
-                diag = up;
-                left = h;
-                Hrow[j] = h;
+            const int h0 = cBeg ? 0 : (int)(-g * rr);
+            int carryU = h0;                       // U(0) = H(rr, 0) + g * 0
+            int diagCarry = h0_prev;
+            for (int jb = 0; jb < n_blocks; ++jb) {
+                const int j = 1 + (jb << 6) + lane;
+                const bool valid = j <= ndb;
+                const int up = valid ? Hrow[j] : kNegInf;
+                int d = __shfl_up(up, 1);
+                if (lane == 0) d = diagCarry;
+                diagCarry = __builtin_amdgcn_readlane(up, 63);
+                int t = kNegInf;
+                if (valid) t = max(d + (int)wrow[c_enc[db[j - 1]]], up - g) + g * j;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(t, off);
+                    if (lane >= off) t = max(t, v);
+                }
+                const int U = max(t, carryU);
+                if (valid) Hrow[j] = U - g * j;
+                carryU = __builtin_amdgcn_readlane(U, 63);   // (lanes behind the last column repeat its U)
             }
-            lastcol = max(lastcol, left);
+            lastcol = max(lastcol, carryU - g * ndb);         // H(rr, ndb)
+            h0_prev = h0;
         }
-        int best = Hrow[ndb], bestj = ndb;
+        // what the sequential scan of the last row returns: the first column that holds the maximum (see the thread-per-
+        // candidate form in the history: `H[j] > best || (H[j] == best && j < bestj && !cEnd)` for j = 1..ndb, from best = H[ndb])
+        int hmax = kNegInf;
+        for (int j = 1 + lane; j <= ndb; j += 64) hmax = max(hmax, Hrow[j]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) hmax = max(hmax, __shfl_xor(hmax, off));
+        int jmin = 0x7fffffff;
+        for (int j = 1 + lane; j <= ndb; j += 64)
+            if (Hrow[j] == hmax) { jmin = j; break; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) jmin = min(jmin, __shfl_xor(jmin, off));
+        int hlast = ((ndb - 1) & 63) == lane ? Hrow[ndb] : kNegInf;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) hlast = max(hlast, __shfl_xor(hlast, off));
+        int best = hlast, bestj = ndb;
         if (cEnd) best = max(best, lastcol);
-        if (dbEnd)
-            for (int j = 1; j <= ndb; ++j)
-                if (Hrow[j] > best || (Hrow[j] == best && j < bestj && !cEnd)) { best = Hrow[j]; bestj = j; }
-        out[0] = best;
-        if (a.ref_mode) out[1] = bestj - 1;
+        if (dbEnd && (hmax > best || (hmax == best && !cEnd))) { best = hmax; bestj = jmin; }
+        if (lane == 0) {
+            out[0] = best;
+            if (a.ref_mode) out[1] = bestj - 1;
+        }
     }
 }
 

@@ -124,8 +124,10 @@ enum Counter {
     kCntBandFallback = kNumLists + 7,     // band reads whose search could not be certified (re-scored exactly)
     kCntMissB = kNumLists + 8,            // [kWinBuckets] loci whose search left the table window, per motif-length bucket
     kCntLociB = kNumLists + 8 + 5,        // [kWinBuckets] loci per motif-length bucket
-    kCntTotal = kNumLists + 8 + 10
+    kCntTotal = kNumLists + 8 + 10,
+    kCntLongNeed = 56                     // the largest scratch slot (int32 units) an item of k_dp_long asked for and did not get
 };
+static_assert(kCntTotal <= 48 && kCntLongNeed < 64, "counters: 64 ints; 45..55 belong to the -DSTRK_PHASE_TIMING aid");
 // motif-length buckets of the adaptive candidate window: 1-2, 3-4, 5-6, 7-10, 11 and more bases (round 4: the two long-motif
 // buckets may go below +-6 — tools/window_need.py: no locus of BASELINE config 4 with a motif of 11+ bases needs more than
 // +-4, 0.7 % of those with 7-10 bases do — and a narrow window is what puts a long motif's band into 256 instead of 384 diagonals)
@@ -146,6 +148,8 @@ __host__ __device__ constexpr int cell_slot_of_list(int c) {
 constexpr int kErrBadInput = 1;   // empty motif / negative length
 constexpr int kErrScratch = 2;    // generic scratch exhausted
 constexpr int kErrEmpty = 4;      // nothing scored for some read
+constexpr int kErrList = 8;       // a class list is full (more items than the call sized its lists for)
+constexpr int kErrLongSlot = 16;  // a window too long for a k_dp_long scratch slot
 constexpr int kSpecMiss = 1, kSpecEmpty = 2;
 
 // ---------------------------------------------------------------------------------------------
@@ -388,7 +392,7 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
                     atomicAdd(&a.wide_hist[wide_slot(band_list - kBandClass0) * 256 + wide_bucket(nfl + (lo + n - 1) * m)], 1);
             }
         } else {
-            atomicOr(&a.counters[kCntError], kErrScratch);
+            atomicOr(&a.counters[kCntError], kErrList);
         }
     }
 }

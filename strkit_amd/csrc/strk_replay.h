@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRK_RE
                                 gl[2 * idx] = rq;
                                 gl[2 * idx + 1] = 0;
                             } else {
-                                atomicOr(&a.counters[kCntError], kErrScratch);
+                                atomicOr(&a.counters[kCntError], kErrList);
                             }
                             atomicAdd(&a.counters[kCntBandFallback], 1);
                             if (cls != kGenericClass) {

@@ -164,6 +164,81 @@ def test_reads_with_more_than_eight_symbol_classes_are_searched_on_the_generic_t
             _compare(b, got, oracle_count(b, 7, 1, 1, 0, 15, feedback))
 
 
+def test_generic_pool_grows_for_a_batch_of_flankless_reads(fresh_ctx):
+    """Reads without a left flank go to the generic kernel, whose H rows live in a pool of 16 Mi ints: 250 loci x 24 such reads
+    of ~750 bases ask for more than that (one row per thread, 65 536 threads).  The call must grow the pool and run again
+    instead of failing with STRK_E_NOMEM — found by tools/fuzz_parity.py (seed 2), where a few hundred ragged loci failed a
+    whole call.  The first and the last loci are checked against the oracle; the score-table entry point takes the same way."""
+    from strkit_amd.batch import score_table
+    rng = np.random.default_rng(20261006)
+    loci = []
+    for _ in range(250):
+        motif = rand_seq(rng, int(rng.integers(2, 7)))
+        fr = rand_seq(rng, 70)
+        cn = int(rng.integers(90, 130))
+        loci.append((motif, [("", motif * (cn + int(rng.integers(-2, 3))), fr) for _ in range(24)]))
+    b = LocusBatch.from_reads(loci)
+    got, st = _run(b, fresh_ctx, dedupe=False)
+    assert st["n_fallback"] == b.n_reads
+    for lo, hi in ((0, 3), (b.n_loci - 2, b.n_loci)):
+        part = b.locus_slice(lo, hi)
+        r0, r1 = int(b.read_off[lo]), int(b.read_off[hi])
+        _compare(part, {k: got[k][r0:r1] for k in KEYS}, oracle_count(part))
+    # the same in a window-miss round: the first read of each locus starts at three times its size, and the widened windows
+    # (hundreds of candidate sizes, one row each) of 200 loci are re-scored together
+    rng = np.random.default_rng(20261007)
+    loci, est = [], []
+    for _ in range(200):
+        motif = rand_seq(rng, int(rng.integers(2, 7)))
+        fr = rand_seq(rng, 70)
+        cn = int(rng.integers(100, 120))
+        loci.append((motif, [("", motif * cn, fr), ("", motif * (cn + 1), fr)]))
+        est.append([3 * cn + 1, cn])
+    bm = LocusBatch.from_reads(loci, est)
+    from strkit_amd import _lib
+    ctx3 = _lib.Context(0)
+    try:
+        gotm, stm = _run(bm, ctx3, dedupe=False, step=5, lsr=2)
+        assert stm["n_miss_reads"] >= 200
+        for lo, hi in ((0, 1), (bm.n_loci - 1, bm.n_loci)):
+            part = bm.locus_slice(lo, hi)
+            r0, r1 = int(bm.read_off[lo]), int(bm.read_off[hi])
+            _compare(part, {k: gotm[k][r0:r1] for k in KEYS}, oracle_count(part, 50, 2, 5))
+    finally:
+        ctx3.close()
+    # the explicit-window entry point on a context of its own (a fresh pool): 31 candidates per read, every read generic
+    ctx2 = _lib.Context(0)
+    try:
+        lo_w = np.maximum(b.est_cn - 15, 0).astype(np.int32)
+        n_w = np.full(b.n_reads, 31, np.int32)
+        tab = score_table(b, lo_w, n_w, ctx=ctx2)
+        import oracle
+        for r in (0, 1, b.n_reads - 1):
+            fl, tr, fr = b.read(r)
+            l = int(np.searchsorted(b.read_off, r, side="right") - 1)
+            exp = [oracle.candidate_score(tr, fl, fr, b.motif(l), int(lo_w[r]) + k) for k in range(31)]
+            assert tab[r].tolist() == exp
+    finally:
+        ctx2.close()
+
+
+def test_long_kernel_slot_grows_for_a_start_far_above_the_tract(fresh_ctx):
+    """A start count of 9 000 copies of an 18-base motif is a candidate of 162 000 rows against a window of 1 100 bases: the long
+    kernel's slot (two boundary columns of one int per row) starts at 48 Ki ints.  In-locus feedback produces such starts from
+    one wild estimate (tools/fuzz_parity.py, seed 2, round 138: the call failed with STRK_E_NOMEM); the context must grow the
+    slots and run the call again."""
+    rng = np.random.default_rng(20261008)
+    motif = rand_seq(rng, 18)
+    fl, fr = rand_seq(rng, 51), rand_seq(rng, 72)
+    b = LocusBatch.from_reads([(motif, [(fl, motif * 55, fr), (fl, motif * 54 + motif[:7], fr)]), ("CAG", [(fl, "CAG" * 20, fr)])],
+                              [[9000, 8000], [20]])
+    got, st = _run(b, fresh_ctx, max_iters=5, feedback=False)
+    assert st["n_long_reads"] >= 2
+    _compare(b, got, oracle_count(b, 5, 3, 1, 0, 15, False))
+    got2, _ = _run(b, fresh_ctx, max_iters=5, feedback=False)      # (the grown context: no second run needed, same answers)
+    _compare(b, got2, got)
+
+
 @pytest.mark.parametrize("flags", list(range(16)))
 def test_band_kernel_under_every_end_flag_mode(gpu_ctx, flags):
     """The banded first pass carries the two free boundaries as table content (pad bytes of the row words, the "no row"
