@@ -55,13 +55,18 @@ std::atomic<int> g_calls_in_flight{0};
 // Default candidate window of this process (one sample, whatever context a call runs on): level into kWindowLevels,
 // and the number of consecutive default-window calls without a window miss since the level last changed.
 // Misses cost extra rounds on the host: a call with more than a handful (> 0.4 % of its loci) moves a level up at
-// once; eight (from the two widest levels: sixty-four) calls in a row with at most one miss per two thousand loci move
-// a level down.
+// once; eight (from the two widest levels: sixty-four) calls in a row with at most one miss per thousand loci move
+// a level down — a probe, whose failures space the later ones out (g_win_failed).
 // One level per motif-length bucket (win_bucket): the estimate round(|tr| / |motif|) is off by the read's indel drift divided
 // by the motif length, so the reads of long motifs stay inside narrow windows that those of short ones leave.  The two
 // narrowest levels (+-4, +-5) are open to the long-motif buckets only (kWinMinLevel).
 std::atomic<int> g_win_level[strk::kWinBuckets] = {{kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}, {kWinStartLevel}};
 std::atomic<int> g_win_quiet[strk::kWinBuckets] = {{0}, {0}, {0}, {0}, {0}};
+// A step down is a probe: the call after it either stays quiet or pays a window-miss round for every locus the narrower window
+// does not hold (config 3, 3-4-base motifs at +-6: 111 loci, 18 ms on top of an 8 ms call) and steps up again.  Every failed
+// probe doubles the number of quiet calls before the next one (64, 128, ... 4 096), per bucket; strk_adaptive_reset clears it.
+std::atomic<int> g_win_probing[strk::kWinBuckets] = {{0}, {0}, {0}, {0}, {0}};   // 1: the level was last changed by a step down
+std::atomic<int> g_win_failed[strk::kWinBuckets] = {{0}, {0}, {0}, {0}, {0}};    // probes that failed since the reset
 
 // The band pass most recently enqueued by any context of this process (its kEvBand event): in whole-grid mode the next call's
 // band pass waits for it (enqueue_scoring), so that two calls in flight run half a period apart whatever their submit times.
@@ -613,14 +618,18 @@ int finish_device(strk_ctx* c, strk_stats* stats) {
             const int level = std::max(kWinMinLevel[k], g_win_level[k].load(std::memory_order_relaxed));
             // a handful of misses costs less (one short extra round) than a wider window for every read does
             // (small calls: two loci of 250 already are 0.8 %, and a window-miss round on long windows costs as much as the call)
+            const int failed = g_win_failed[k].load(std::memory_order_relaxed);
+            const int quiet_calls = failed > 0 ? 64 << std::min(failed - 1, 6) : (level > kWinStartLevel ? 64 : 8);
             if (n_miss > std::max(1, n_loci_k / 250)) {
                 if (level < kWinLevels - 1) g_win_level[k].store(level + 1, std::memory_order_relaxed);
-                g_win_quiet[k].store(level < kWinStartLevel ? -56 : 0, std::memory_order_relaxed);   // a failed narrow window is not retried soon
+                if (g_win_probing[k].exchange(0, std::memory_order_relaxed)) g_win_failed[k].store(std::min(failed + 1, 16), std::memory_order_relaxed);
+                g_win_quiet[k].store(0, std::memory_order_relaxed);
             } else if (n_miss > n_loci_k / 1000) {   // more than one locus in a thousand: not a quiet call
                 g_win_quiet[k].store(0, std::memory_order_relaxed);
-            } else if (g_win_quiet[k].fetch_add(1, std::memory_order_relaxed) + 1 >= (level > kWinStartLevel ? 64 : 8) && level > kWinMinLevel[k]) {
+            } else if (g_win_quiet[k].fetch_add(1, std::memory_order_relaxed) + 1 >= quiet_calls && level > kWinMinLevel[k]) {
                 g_win_level[k].store(level - 1, std::memory_order_relaxed);
                 g_win_quiet[k].store(0, std::memory_order_relaxed);
+                g_win_probing[k].store(1, std::memory_order_relaxed);
             }
         }
     }
@@ -887,6 +896,8 @@ void strk_adaptive_reset(void) {
     for (int k = 0; k < strk::kWinBuckets; ++k) {
         g_win_level[k].store(kWinStartLevel, std::memory_order_relaxed);
         g_win_quiet[k].store(0, std::memory_order_relaxed);
+        g_win_probing[k].store(0, std::memory_order_relaxed);
+        g_win_failed[k].store(0, std::memory_order_relaxed);
     }
 }
 

@@ -32,13 +32,17 @@ t = {k: torch.from_numpy(getattr(b, k)).to(dev) for k in ("seqs", "seq_off", "nf
 sb = _lib.StrkBatch(n_reads=b.n_reads, n_loci=b.n_loci, **{k: v.data_ptr() for k, v in t.items()})
 out = torch.zeros((4, b.n_reads), dtype=torch.int32, device=dev)
 ctx = _lib.Context(0)
-p = make_params(band=False)
+band_on = os.environ.get("LONG_PROBE_BAND", "0") == "1"      # LONG_PROBE_BAND=1: the banded first pass stays on
+p = make_params(band=band_on)
 st = _lib.StrkStats()
+import time  # noqa: E402
 for i in range(n_calls):
+    t0 = time.perf_counter()
     _lib.check(L.strk_count_loci_device(ctx.handle, C.byref(sb), C.byref(p), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
                                         out[3].data_ptr(), None, C.byref(st)))
     d = st.as_dict()
-    print(f"call {i}: kernel {d['kernel_ms']:.2f} ms | exact {d['dp_kernel_ms']:.2f} ms ({d['exact_cells']:.3g} cells) | long {d['long_kernel_ms']:.2f} ms "
+    d["wall"] = (time.perf_counter() - t0) * 1e3
+    print(f"call {i}: wall {d['wall']:.1f} ms, miss rounds {d['n_miss_rounds']}, window {d['window_bucket']} | kernel {d['kernel_ms']:.2f} ms | exact {d['dp_kernel_ms']:.2f} ms ({d['exact_cells']:.3g} cells) | long {d['long_kernel_ms']:.2f} ms "
           f"({d['long_cells']:.3g} cells, {d['n_long_reads']} items) -> long {d['long_cells'] / max(d['long_kernel_ms'], 1e-9) / 1e6:.0f} G cells/s, "
           f"exact {d['exact_cells'] / max(d['dp_kernel_ms'], 1e-9) / 1e6:.0f} G cells/s | miss {d['n_miss_reads']} dedup {d['n_dedup_reads']}", flush=True)
 if n_check:
