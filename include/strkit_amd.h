@@ -58,7 +58,10 @@ extern "C" {
 
 #define STRK_TIE_FIRST 0 /* Python max(): first maximal element (repeats.py:135,154) */
 #define STRK_TIE_LAST 1
-#define STRK_NARROW_NONE 0
+#define STRK_NARROW_NONE 0       /* local_search_range fixed for the whole search (repeats.py:100-151) */
+#define STRK_NARROW_DECREMENT 1  /* one less after every explored stack entry, never below 1 */
+#define STRK_NARROW_HALVE 2      /* halved after every explored stack entry, never below 1 */
+#define STRK_NARROW_AFTER_SEED 3 /* the three seed entries use it as given, every chased entry 1 */
 
 typedef struct strk_ctx strk_ctx;
 
@@ -88,10 +91,12 @@ typedef struct strk_params {
     int32_t narrowing;          /* schedule by which local_search_range / step_size shrink inside one search
                                    (repeat_count_params.py:14: "can be narrowed within the get_repeat_count fn").
                                    STRK_NARROW_NONE (0): fixed for the whole search, as get_ref_repeat_count does
-                                   (repeats.py:100-151) — the only schedule the tree states.  Any other value is rejected
-                                   with STRK_E_INVALID: the field exists so that a sweep (tools/compare_strkit_json.py) can
-                                   name the switch once the Rust function's schedule is known; search_replay() is the one
-                                   place it would change. */
+                                   (repeats.py:100-151) — the only schedule the tree states, and the default.  The Rust
+                                   function's own schedule is not in the tree; STRK_NARROW_DECREMENT / _HALVE / _AFTER_SEED
+                                   are the plausible forms (strk_search.h: LsrSchedule; step_size stays fixed in all of
+                                   them), there so that reference vectors (tests/test_reference_vectors.py) or a report
+                                   diff (tools/compare_strkit_json.py) can name the one that fits.  Other values:
+                                   STRK_E_INVALID.  The scalar entry point strk_repeat_count always runs STRK_NARROW_NONE. */
 } strk_params;
 
 /* CSR-packed batch of loci.  Read r owns seqs[seq_off[r] .. seq_off[r+1]) laid out fl|tr|fr;

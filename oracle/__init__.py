@@ -101,8 +101,10 @@ def candidate_score(tr, fl, fr, motif, i: int, flags: int = SG_ALL) -> int:
 
 
 def repeat_count(start_count: int, tr, fl, fr, motif, max_iters: int = 50, lsr: int = 3, step: int = 1,
-                 tie_rule: int = TIE_FIRST, flags: int = SG_ALL, with_cells: bool = False):
-    """Reference contract (repeats.py:55-56): ((cn, score), n_explored, cn - start_count)."""
+                 tie_rule: int = TIE_FIRST, flags: int = SG_ALL, with_cells: bool = False, narrowing: int = 0):
+    """Reference contract (repeats.py:55-56): ((cn, score), n_explored, cn - start_count).
+    `narrowing`: how local_search_range changes inside the search (strk_oracle.c: 0 fixed, the default; 1 / 2 / 3)."""
+    tie_rule = (tie_rule & 1) | ((narrowing & 3) << 8)
     bt, nt = _b(tr); bl, nl = _b(fl); br, nr = _b(fr); bm, nm = _b(motif)
     cn, sc, n, cells = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
     rc = lib().strk_o_repeat_count(start_count, bt, nt, bl, nl, br, nr, bm, nm, max_iters, lsr, step, tie_rule,
@@ -115,11 +117,12 @@ def repeat_count(start_count: int, tr, fl, fr, motif, max_iters: int = 50, lsr: 
 
 def count_locus(seqs: np.ndarray, off: np.ndarray, nfl: np.ndarray, ntr: np.ndarray, nfr: np.ndarray,
                 est_cn: np.ndarray, motif, max_iters: int = 50, lsr: int = 3, step: int = 1,
-                tie_rule: int = TIE_FIRST, flags: int = SG_ALL, feedback: bool = True, memo: bool = False):
+                tie_rule: int = TIE_FIRST, flags: int = SG_ALL, feedback: bool = True, memo: bool = False, narrowing: int = 0):
     """One locus, reads in order with the caller's start-count feedback (call_locus.py:1125-1161).
 
     Returns dict of int32 arrays cn, score, n_iters, start and the DP cell count."""
     n = len(nfl)
+    tie_rule = (tie_rule & 1) | ((narrowing & 3) << 8)
     seqs = np.ascontiguousarray(seqs, np.uint8)
     off = np.ascontiguousarray(off, np.int64)
     nfl = np.ascontiguousarray(nfl, np.int32); ntr = np.ascontiguousarray(ntr, np.int32)

@@ -286,7 +286,14 @@ static void omap_put(omap* m, int32_t key, int32_t val) {
  * Defaults (none confirmable from /root/reference): n_explored counts newly
  * scored sizes (repeats.py:130); window rule repeats.py:114-117; tie rule first-max.
  * Returns 0, or -1 if nothing could be scored (Python's max() of an empty dict would raise).
+ *
+ * `tie_rule` is a rule word: bit 0 = STRK_O_TIE_LAST; bits 8-9 = how local_search_range changes inside the search — the
+ * reference calls it an INITIAL value that "can be narrowed within the get_repeat_count fn" (repeat_count_params.py:14) and
+ * the function is not in the tree.  0: fixed (the in-tree sibling's way, the default); 1: one less after every explored stack
+ * entry, never below 1; 2: halved after every explored entry, never below 1; 3: the three seed entries use it as given, every
+ * chased entry 1.  An explored entry is one popped with size >= 0.  (Same modes as the product's STRK_NARROW_*.)
  */
+#define STRK_O_NARROW_OF(rule) (((rule) >> 8) & 3)
 int strk_o_repeat_count(int32_t start_count, const uint8_t* tr, int32_t ntr, const uint8_t* fl,
                         int32_t nfl, const uint8_t* fr, int32_t nfr, const uint8_t* motif,
                         int32_t m, int32_t max_iters, int32_t lsr, int32_t step, int32_t tie_rule,
@@ -306,10 +313,18 @@ int strk_o_repeat_count(int32_t start_count, const uint8_t* tr, int32_t ntr, con
     st_size[sp] = start_count + step; st_dir[sp++] = 1;
     st_size[sp] = start_count;        st_dir[sp++] = 0;
     int32_t n = 0;
+    const int32_t narrow = STRK_O_NARROW_OF(tie_rule), lsr_given = lsr, lsr_floor = lsr < 1 ? lsr : 1;
+    int32_t lsr_cur = lsr, seeds = 3;   /* stack entries below depth `seeds` are the initial three */
+    tie_rule &= 1;
     while (sp > 0 && n < max_iters) {
         sp--;
         int32_t size = st_size[sp], dir = st_dir[sp];
+        const int is_seed = sp < seeds;
+        if (is_seed) seeds = sp;
         if (size < 0) continue;
+        lsr = narrow == 3 ? (is_seed ? lsr_given : lsr_floor) : lsr_cur;
+        if (narrow == 1) lsr_cur = lsr_cur - 1 > lsr_floor ? lsr_cur - 1 : lsr_floor;
+        if (narrow == 2) lsr_cur = (lsr_cur >> 1) > lsr_floor ? (lsr_cur >> 1) : lsr_floor;
         int32_t lo = size - ((dir < 1 || step > lsr) ? lsr : 0);
         if (lo < 0) lo = 0;
         int32_t hi = size + ((dir > -1 || step > lsr) ? lsr : 0);
@@ -466,6 +481,9 @@ int strk_o_ref_repeat_count(int32_t start_count, const uint8_t* tr, int32_t ntr,
     memcpy(db + nfl, tr, (size_t)ntr);
     memcpy(db + nfl + ntr, fr, (size_t)nfr);
     int32_t l_offset = 0, r_offset = 0, n_off = 0;
+    /* the boundary search below IS the in-tree code (fixed range): only the final read-side call takes the whole rule word */
+    const int32_t rule_word = tie_rule;
+    tie_rule &= 1;
 
     if (!respect_coords) {
         /* fwd / rev maps are always filled together (repeats.py:123-128) so one key list */
@@ -534,7 +552,7 @@ int strk_o_ref_repeat_count(int32_t start_count, const uint8_t* tr, int32_t ntr,
     int32_t start2 = (int32_t)py_round(((double)((int64_t)start_count * m + lo_pos + ro_pos)) / (double)m);
     int32_t cn = 0, sc = 0, n = 0;
     int rc = strk_o_repeat_count(start2, db + nfl2, ntr2, db, nfl2, db + nfl2 + ntr2, nfr2, motif, m,
-                                 max_iters, lsr, step, tie_rule, flags, &cn, &sc, &n, NULL);
+                                 max_iters, lsr, step, rule_word, flags, &cn, &sc, &n, NULL);
     out[0] = cn; out[1] = sc; out[2] = l_offset; out[3] = r_offset; out[4] = n_off; out[5] = n;
     out[6] = nfl2; out[7] = ntr2; out[8] = nfr2;
     free(db);

@@ -13,7 +13,7 @@ from . import _build
 
 STRK_SG_ALL = 15
 STRK_TIE_FIRST, STRK_TIE_LAST = 0, 1
-STRK_NARROW_NONE = 0
+STRK_NARROW_NONE, STRK_NARROW_DECREMENT, STRK_NARROW_HALVE, STRK_NARROW_AFTER_SEED = 0, 1, 2, 3
 STRK_I16_CELL_MAY_SATURATE, STRK_I16_SCORE_SATURATES = 1, 2
 STRK_E_EMPTY = -61
 STRK_E_INVALID, STRK_E_NOMEM, STRK_E_DEVICE, STRK_E_NODEV = -22, -12, -5, -19

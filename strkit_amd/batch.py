@@ -61,10 +61,10 @@ def unpin_batch(b: LocusBatch) -> None:
 
 def count_loci(b: LocusBatch, rc_params: RepeatCountParams | None = None, feedback: bool = True, window: int = 0,
                tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL, ctx: _lib.Context | None = None,
-               with_stats: bool = False, dedupe: bool = True, band: bool = True):
+               with_stats: bool = False, dedupe: bool = True, band: bool = True, narrowing: int = _lib.STRK_NARROW_NONE):
     """Per-read (cn, score, n_iters, start) for every read of the batch, as int32 arrays."""
     ctx = ctx or _lib.default_context()
-    p = make_params(rc_params, feedback, window, tie_rule, end_flags, dedupe, band)
+    p = make_params(rc_params, feedback, window, tie_rule, end_flags, dedupe, band, narrowing)
     s, keep = batch_struct(b)
     n = max(b.n_reads, 1)
     out = {k: np.zeros(n, np.int32) for k in ("cn", "score", "n_iters", "start")}

@@ -224,9 +224,10 @@ int check_params(const strk_params* p, strk_params* out) {
         return fail(STRK_E_INVALID, "local_search_range must be >= 0 and step_size >= 1");
     if (out->tie_rule != STRK_TIE_FIRST && out->tie_rule != STRK_TIE_LAST) return fail(STRK_E_INVALID, "bad tie_rule");
     if (out->end_flags < 0 || out->end_flags > 15) return fail(STRK_E_INVALID, "bad end_flags");
-    if (out->narrowing != STRK_NARROW_NONE)
-        return fail(STRK_E_INVALID, "narrowing schedule %d is not implemented (only STRK_NARROW_NONE: the search parameters stay fixed, "
-                                    "as in get_ref_repeat_count)", out->narrowing);
+    static_assert(STRK_NARROW_NONE == strk::kNarrowNone && STRK_NARROW_DECREMENT == strk::kNarrowDecrement &&
+                  STRK_NARROW_HALVE == strk::kNarrowHalve && STRK_NARROW_AFTER_SEED == strk::kNarrowAfterSeed, "include/strkit_amd.h <-> strk_search.h");
+    if (out->narrowing < 0 || out->narrowing >= strk::kNarrowModes)
+        return fail(STRK_E_INVALID, "narrowing schedule %d is not one of STRK_NARROW_NONE / _DECREMENT / _HALVE / _AFTER_SEED", out->narrowing);
     return 0;
 }
 
@@ -295,6 +296,7 @@ KArgs make_args(strk_ctx* c, const strk_batch* b, int end_flags, int window, int
         a.spec = static_cast<int4*>(c->spec.p);
         a.max_iters = sp->max_iters; a.lsr = sp->local_search_range; a.step = sp->step_size;
         a.tie_last = sp->tie_rule == STRK_TIE_LAST;
+        a.narrow = sp->narrowing;
         a.rep = c->rep.as<int32_t>();
         a.rhash = sp->no_dedupe ? nullptr : c->rhash.as<unsigned long long>();
         a.exact = c->exact.as<uint8_t>();
@@ -505,7 +507,7 @@ int submit_device(strk_ctx* c, const strk_batch* b, const strk_params* params, i
     KArgs a = make_args(c, b, p.end_flags, p.window, ts, b->n_reads, &p);
     ReplayArgs rp;
     rp.max_iters = p.max_iters; rp.lsr = p.local_search_range; rp.step = p.step_size;
-    rp.tie_last = p.tie_rule == STRK_TIE_LAST; rp.feedback = p.feedback;
+    rp.tie_last = p.tie_rule == STRK_TIE_LAST; rp.feedback = p.feedback; rp.narrow = p.narrowing;
     rp.out_cn = out_cn; rp.out_score = out_score; rp.out_n = out_n; rp.out_start = out_start;
     rp.next_read = c->state_i32.as<int32_t>();
     rp.need_lo = rp.next_read + b->n_loci;

@@ -514,7 +514,7 @@ __device__ __forceinline__ void band_wave(const KArgs& a, bool act, int4 q0, int
         if (run && !(a.dbg & 4)) {
             SeenMask64 seen;
             auto ub = [&](int k) { return ubA[k]; };
-            const CertResult cr = search_replay_cert(q2.w, a.step, a.lsr, a.max_iters, a.tie_last, comb, lo, n, seen, ub);
+            const CertResult cr = search_replay_cert(q2.w, a.step, a.lsr, a.max_iters, a.tie_last, comb, lo, n, seen, ub, a.narrow);
             if (!cr.uncertain) {
                 certified = true;
                 a.spec[r] = make_int4(cr.res.cn, cr.res.score, cr.res.n_explored,

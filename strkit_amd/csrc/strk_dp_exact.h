@@ -541,7 +541,7 @@ __device__ __forceinline__ void dp_wave(KArgsKernarg ap, int cls, int base, uint
     int4* const spec = ap2->spec;
     if (spec && !ref_mode && act && first && k0 == 0) {
         SeenMask64 seen;
-        const SearchResult res = search_replay(ap2->est_cn[r], ap2->step, ap2->lsr, ap2->max_iters, ap2->tie_last, comb, lo, n, seen);
+        const SearchResult res = search_replay(ap2->est_cn[r], ap2->step, ap2->lsr, ap2->max_iters, ap2->tie_last, comb, lo, n, seen, ap2->narrow);
         spec[r] = make_int4(res.cn, res.score, res.n_explored, (res.miss ? kSpecMiss : 0) | (res.empty ? kSpecEmpty : 0));
     }
     wave_lds_sync();

@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) k_dp_long(KArgs a) {
         wave_lds_sync();
         if (a.spec && first && k0 == 0) {
             SeenMask64 seen;
-            const SearchResult res = search_replay(a.est_cn[r], a.step, a.lsr, a.max_iters, a.tie_last, comb, lo, n, seen);
+            const SearchResult res = search_replay(a.est_cn[r], a.step, a.lsr, a.max_iters, a.tie_last, comb, lo, n, seen, a.narrow);
             a.spec[r] = make_int4(res.cn, res.score, res.n_explored, (res.miss ? kSpecMiss : 0) | (res.empty ? kSpecEmpty : 0));
         }
         wave_lds_sync();

@@ -103,6 +103,7 @@ struct KArgs {
                           //    indel drift DIVIDED by the motif length, so long motifs get by with narrow windows
     int32_t table_stride; // entries per read (plan kernel)
     int32_t max_iters, lsr, step, tie_last;  // search parameters (speculative search in k_dp_all)
+    int32_t narrow;                          // schedule of local_search_range inside one search (strk_search.h: kNarrow*)
     int32_t band_mode;    // 1: eligible reads go through k_dp_band first (strk_search.h, "Banded scoring")
     int32_t band_limit;   // only reads with index < band_limit are eligible (a context on probation tries the band on a sample)
     BandTune band_tune;   // where the forward band lies (strk_search.h: band_geometry)

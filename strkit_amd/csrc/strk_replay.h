@@ -9,7 +9,7 @@ namespace strk {
 // start-count feedback (call_locus.py:1129-1136,1161) and replays the hill climb on the table.
 // ---------------------------------------------------------------------------------------------
 struct ReplayArgs {
-    int32_t max_iters, lsr, step, tie_last, feedback;
+    int32_t max_iters, lsr, step, tie_last, feedback, narrow;
     int32_t* out_cn;
     int32_t* out_score;
     int32_t* out_n;
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRK_RE
                 }
                 if (is_exact) {
                     res = search_replay(start, p.step, p.lsr, p.max_iters, p.tie_last, a.table + a.tab_off[r], a.win_lo[r],
-                                        min(a.win_n[r], 64), seen);
+                                        min(a.win_n[r], 64), seen, p.narrow);
                 } else {
                     // banded table: lower bounds + certificate; an ambiguous comparison asks for exact scores
                     const int nfl = a.nfl[rp], ntr = a.ntr[rp], nfr = a.nfr[rp];
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STRK_RE
                     const int flags = a.end_flags;
                     auto ub = [&](int k) { return band_ub(geo, nfl, ntr, nfr, m, wlo + k, flags); };
                     const CertResult cr = search_replay_cert(start, p.step, p.lsr, p.max_iters, p.tie_last,
-                                                             a.table + a.tab_off[r], wlo, wn, seen, ub);
+                                                             a.table + a.tab_off[r], wlo, wn, seen, ub, p.narrow);
                     res = cr.res;
                     if (cr.uncertain && p.pre_exact) {
                         // this read and the rest of the locus go to the exact kernels (every read at most once: test-and-set of

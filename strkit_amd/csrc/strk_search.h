@@ -30,12 +30,33 @@ struct SearchResult {
     int32_t empty;             // 1: nothing was scored (Python's max() would raise)
 };
 
+// How local_search_range changes inside one search.  The reference calls its search parameters INITIAL values that "can be
+// narrowed within the get_repeat_count fn" (strkit/call/repeat_count_params.py:14); the function itself is not in the tree, so
+// which schedule it follows is unknown.  0 keeps the range fixed, as the in-tree sibling
+// get_ref_repeat_count does (the default); the others are the plausible forms, selectable so that reference vectors
+// (tests/test_reference_vectors.py) can name the one that fits:
+//   1  one less after every explored stack entry (never below 1);
+//   2  halved after every explored stack entry (never below 1);
+//   3  the three seed entries [(s-step,-1),(s+step,+1),(s,0)] use the initial range, every chased entry 1.
+// An explored entry is one that was popped with a size >= 0.  step_size stays fixed (the read side runs with 1).
+constexpr int32_t kNarrowNone = 0, kNarrowDecrement = 1, kNarrowHalve = 2, kNarrowAfterSeed = 3, kNarrowModes = 4;
+struct LsrSchedule {
+    int32_t mode, lsr, cur;
+    STRK_HD LsrSchedule(int32_t mode_, int32_t lsr_) : mode(mode_), lsr(lsr_), cur(lsr_) {}
+    STRK_HD int32_t floor1() const { return lsr < 1 ? lsr : 1; }
+    STRK_HD int32_t at(bool seed) const { return mode == kNarrowAfterSeed ? (seed ? lsr : floor1()) : cur; }
+    STRK_HD void explored() {
+        if (mode == kNarrowDecrement) cur = cur - 1 > floor1() ? cur - 1 : floor1();
+        else if (mode == kNarrowHalve) cur = (cur >> 1) > floor1() ? (cur >> 1) : floor1();
+    }
+};
+
 // View of one read's score table: scores[k] = score of candidate size lo + k, k < n.
 // `seen` must provide test(k) / set(k) for k < n, initially all clear.
 template <class Seen>
-STRK_HD SearchResult search_replay(int32_t start, int32_t step, int32_t lsr, int32_t max_iters,
+STRK_HD SearchResult search_replay(int32_t start, int32_t step, int32_t lsr0, int32_t max_iters,
                                    int32_t tie_last, const int32_t* scores, int32_t lo, int32_t n,
-                                   Seen& seen) {
+                                   Seen& seen, int32_t narrow = kNarrowNone) {
     SearchResult res = {0, 0, 0, 0, 0, 0, 0};
     int64_t st_size[4];
     int32_t st_dir[4];
@@ -43,14 +64,20 @@ STRK_HD SearchResult search_replay(int32_t start, int32_t step, int32_t lsr, int
     st_size[sp] = (int64_t)start - step; st_dir[sp++] = -1;
     st_size[sp] = (int64_t)start + step; st_dir[sp++] = 1;
     st_size[sp] = start;                 st_dir[sp++] = 0;
+    int seeds = 3;                       // the entries below this stack depth are seeds (nothing is pushed under them)
     bool have_best = false;
     int32_t best_i = 0, best_s = 0, n_scored = 0;
-    const bool widen = step > lsr;
+    LsrSchedule sched(narrow, lsr0);
     while (sp > 0 && n_scored < max_iters) {
         --sp;
         const int64_t size = st_size[sp];
         const int32_t dir = st_dir[sp];
+        const bool seed = sp < seeds;
+        if (seed) seeds = sp;
         if (size < 0) continue;
+        const int32_t lsr = sched.at(seed);
+        sched.explored();
+        const bool widen = step > lsr;
         int64_t w_lo = size - ((dir < 1 || widen) ? lsr : 0);
         if (w_lo < 0) w_lo = 0;
         const int64_t w_hi = size + ((dir > -1 || widen) ? lsr : 0);
@@ -285,8 +312,9 @@ struct CertResult {
 };
 
 template <class Seen, class Ub>
-STRK_HD CertResult search_replay_cert(int32_t start, int32_t step, int32_t lsr, int32_t max_iters, int32_t tie_last,
-                                      const int32_t* scores, int32_t lo, int32_t n, Seen& seen, const Ub& ub) {
+STRK_HD CertResult search_replay_cert(int32_t start, int32_t step, int32_t lsr0, int32_t max_iters, int32_t tie_last,
+                                      const int32_t* scores, int32_t lo, int32_t n, Seen& seen, const Ub& ub,
+                                      int32_t narrow = kNarrowNone) {
     CertResult out = {{0, 0, 0, 0, 0, 0, 0}, 0};
     SearchResult& res = out.res;
     int64_t st_size[4];
@@ -298,12 +326,18 @@ STRK_HD CertResult search_replay_cert(int32_t start, int32_t step, int32_t lsr, 
     bool have_best = false;
     int32_t best_i = 0, best_s = 0, n_scored = 0;
     int32_t max_inexact = -(1 << 30);   // largest upper bound among the inexact entries scored so far
-    const bool widen = step > lsr;
+    int seeds = 3;
+    LsrSchedule sched(narrow, lsr0);
     while (sp > 0 && n_scored < max_iters) {
         --sp;
         const int64_t size = st_size[sp];
         const int32_t dir = st_dir[sp];
+        const bool seed = sp < seeds;
+        if (seed) seeds = sp;
         if (size < 0) continue;
+        const int32_t lsr = sched.at(seed);
+        sched.explored();
+        const bool widen = step > lsr;
         int64_t w_lo = size - ((dir < 1 || widen) ? lsr : 0);
         if (w_lo < 0) w_lo = 0;
         const int64_t w_hi = size + ((dir > -1 || widen) ? lsr : 0);

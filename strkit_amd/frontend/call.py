@@ -45,6 +45,7 @@ class CallOptions:
     min_read_align_score: float = MIN_READ_ALIGN_SCORE
     tie_rule: int = _lib.STRK_TIE_FIRST
     end_flags: int = _lib.STRK_SG_ALL
+    narrowing: int = _lib.STRK_NARROW_NONE
 
 
 MAX_READS = 250                 # params.max_reads default (strkit/call/params.py:21)
@@ -222,10 +223,11 @@ def _locus_dict(locus: Locus) -> dict:
 def call_locus(locus: Locus, bam: BamFile, ref: Fasta, flank_size: int = 70, realign: bool = False,
                min_avg_phred: int = MIN_AVG_PHRED, max_reads: int = MAX_READS, respect_ref: bool = False,
                rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE,
-               ctx: _lib.Context | None = None, tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL) -> dict:
+               ctx: _lib.Context | None = None, tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL,
+               narrowing: int = _lib.STRK_NARROW_NONE) -> dict:
     """The per-locus entry point (strkit/call/call_locus.py:974-995) over this backend: one locus, its LocusResult
     record up to the read records (a block of one through the same path as call_sample)."""
-    opts = CallOptions(flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params, min_read_align_score, tie_rule, end_flags)
+    opts = CallOptions(flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params, min_read_align_score, tie_rule, end_flags, narrowing)
     return call_blocks([[locus]], bam, ref, opts, ctx)[0][0]
 
 
@@ -234,7 +236,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
                 sample_id: str | None = None, ctx: _lib.Context | None = None, processes: int = 1,
                 rc_params: RepeatCountParams | None = None, min_read_align_score: float = MIN_READ_ALIGN_SCORE,
                 tie_rule: int = _lib.STRK_TIE_FIRST, end_flags: int = _lib.STRK_SG_ALL, front_end: str = "auto",
-                span_bytes: int = 4 << 30) -> dict:
+                span_bytes: int = 4 << 30, narrowing: int = _lib.STRK_NARROW_NONE) -> dict:
     """`front_end` (for a `bam` given as a path): "device" = the file is inflated, scanned and cut on the GPU (DeviceBam) —
     whole when the compressed bytes plus their decompressed form (taken as `RESIDENT_FACTOR` times the file) fit into 90 % of
     the device memory that is free right now, else, with a .bai, in spans of at most `span_bytes` compressed bytes that follow
@@ -292,7 +294,7 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
         else:
             bam = IndexedBam(bam) if has_index else NativeBam(bam)
     t_open = time.perf_counter() - t_open       # (device reader: replaced below by the time its thread took)
-    opts = CallOptions(flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params, min_read_align_score, tie_rule, end_flags)
+    opts = CallOptions(flank_size, realign, min_avg_phred, max_reads, respect_ref, rc_params, min_read_align_score, tie_rule, end_flags, narrowing)
     try:
         ref = Fasta(ref) if isinstance(ref, str) else ref
         t0 = time.perf_counter()
@@ -359,7 +361,8 @@ def call_sample(bam: BamFile | str, ref: Fasta | str, loci_file: str, flank_size
                            "max_reads": max_reads, "respect_ref": respect_ref, "rc_method": "repalign",
                            "min_read_align_score": min_read_align_score, "processes": processes,
                            **({"tie_rule": tie_rule} if tie_rule != _lib.STRK_TIE_FIRST else {}),
-                           **({"end_flags": end_flags} if end_flags != _lib.STRK_SG_ALL else {})},
+                           **({"end_flags": end_flags} if end_flags != _lib.STRK_SG_ALL else {}),
+                           **({"narrowing": narrowing} if narrowing != _lib.STRK_NARROW_NONE else {})},
             "contigs": sorted({r["contig"] for r in results}),
             "catalog": {"num_loci": len(results), "num_loci_unknown_contig": n_catalog - n_loaded},
             "results": results,
@@ -637,7 +640,7 @@ def _empty_counts(n_loci):
 def _count(batch: LocusBatch, opts: CallOptions, ctx, tm=None):
     if not batch.n_reads:
         return _empty_counts(batch.n_loci)
-    out = count_loci(batch, opts.rc_params, ctx=ctx, tie_rule=opts.tie_rule, end_flags=opts.end_flags, with_stats=tm is not None)
+    out = count_loci(batch, opts.rc_params, ctx=ctx, tie_rule=opts.tie_rule, end_flags=opts.end_flags, narrowing=opts.narrowing, with_stats=tm is not None)
     res = out
     if tm is not None and isinstance(out, tuple):
         res, st = out

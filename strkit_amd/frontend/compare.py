@@ -83,18 +83,23 @@ def diff_reports(theirs: dict, ours: dict, sc_tol: float = 1e-9, max_diffs: int 
     return out
 
 
-def sweep(theirs: dict, run: Callable[[int, int], dict], end_flags: Iterable[int] = range(16),
-          tie_rules: Iterable[int] = (0, 1)) -> list[dict]:
-    """`run(end_flags, tie_rule) -> our report`; one row per combination, best first (most per-read copy numbers
-    reproduced, then most scores).  The read side's switches do not touch ref_cn / start_adj / end_adj."""
+def sweep(theirs: dict, run: Callable[..., dict], end_flags: Iterable[int] = range(16),
+          tie_rules: Iterable[int] = (0, 1), narrowings: Iterable[int] = (0,)) -> list[dict]:
+    """`run(end_flags, tie_rule[, narrowing]) -> our report`; one row per combination, best first (most per-read copy numbers
+    reproduced, then most scores).  The read side's switches do not touch ref_cn / start_adj / end_adj.  `narrowings`: the
+    schedules of local_search_range to try (STRK_NARROW_*; `run` gets the third argument only when more than the default 0
+    is asked for) — a report holds no iteration counts, so a schedule shows only where it ends the search on another size."""
     rows = []
+    narrowings = tuple(narrowings)
     for ef in end_flags:
         for tr in tie_rules:
-            d = diff_reports(theirs, run(ef, tr), max_diffs=0)
-            rows.append({"end_flags": ef, "tie_rule": tr, "cn_equal": d["cn_equal"], "sc_equal": d["sc_equal"],
-                         "reads_common": d["reads_common"], "reads_only_theirs": d["reads_only_theirs"],
-                         "reads_only_ours": d["reads_only_ours"], "identical": d["identical"]})
-    rows.sort(key=lambda r: (-r["cn_equal"], -r["sc_equal"], r["reads_only_theirs"] + r["reads_only_ours"], r["end_flags"], r["tie_rule"]))
+            for nw in narrowings:
+                d = diff_reports(theirs, run(ef, tr) if narrowings == (0,) else run(ef, tr, nw), max_diffs=0)
+                rows.append({"end_flags": ef, "tie_rule": tr, "narrowing": nw, "cn_equal": d["cn_equal"], "sc_equal": d["sc_equal"],
+                             "reads_common": d["reads_common"], "reads_only_theirs": d["reads_only_theirs"],
+                             "reads_only_ours": d["reads_only_ours"], "identical": d["identical"]})
+    rows.sort(key=lambda r: (-r["cn_equal"], -r["sc_equal"], r["reads_only_theirs"] + r["reads_only_ours"], r["end_flags"], r["tie_rule"],
+                             r["narrowing"]))
     return rows
 
 

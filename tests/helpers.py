@@ -56,7 +56,7 @@ def oracle_table(b: LocusBatch, lo, n, flags=15):
     return out
 
 
-def oracle_count(b: LocusBatch, max_iters=50, lsr=3, step=1, tie_rule=0, flags=15, feedback=True):
+def oracle_count(b: LocusBatch, max_iters=50, lsr=3, step=1, tie_rule=0, flags=15, feedback=True, narrowing=0):
     res = {k: np.zeros(b.n_reads, np.int32) for k in ("cn", "score", "n_iters", "start")}
     for l in range(b.n_loci):
         r0, r1 = int(b.read_off[l]), int(b.read_off[l + 1])
@@ -65,10 +65,57 @@ def oracle_count(b: LocusBatch, max_iters=50, lsr=3, step=1, tie_rule=0, flags=1
         s0 = int(b.seq_off[r0])
         o = oracle.count_locus(b.seqs[s0:int(b.seq_off[r1])], b.seq_off[r0:r1 + 1] - s0, b.nfl[r0:r1], b.ntr[r0:r1],
                                b.nfr[r0:r1], b.est_cn[r0:r1], b.motif(l), max_iters, lsr, step, tie_rule, flags,
-                               feedback)
+                               feedback, narrowing=narrowing)
         for k in res:
             res[k][r0:r1] = o[k]
     return res
+
+
+def py_search(start, step, lsr, max_iters, tie_last, narrow, table):
+    """The read-side search as a plain Python loop over a {size: score} table (control flow of repeats.py:100-151 as
+    strk_search.h states it), with the schedules of local_search_range the library offers (strk_search.h: LsrSchedule).
+    Written from the description, not from the C++: (cn, score, n_explored), or "miss" when a size outside the table is needed,
+    "empty" when nothing was scored."""
+    to_explore = [(start - step, -1, True), (start + step, 1, True), (start, 0, True)]
+    seen = {}
+    floor1 = min(lsr, 1)
+    cur = lsr
+    n = 0
+    while to_explore and n < max_iters:
+        size, direction, seed = to_explore.pop()
+        if size < 0:
+            continue
+        use = (lsr if seed else floor1) if narrow == 3 else cur
+        if narrow == 1:
+            cur = max(floor1, cur - 1)
+        elif narrow == 2:
+            cur = max(floor1, cur // 2)
+        both = step > use
+        w_lo = max(0, size - (use if (direction < 1 or both) else 0))
+        w_hi = size + (use if (direction > -1 or both) else 0)
+        szs = []
+        for i in range(w_lo, w_hi + 1):
+            if i not in table:
+                return "miss"
+            if i not in seen:
+                seen[i] = table[i]
+                n += 1
+            szs.append((i, table[i]))
+        mv = szs[0]
+        for x in szs[1:]:
+            if x[1] > mv[1] or (tie_last and x[1] == mv[1]):
+                mv = x
+        if mv[0] > size and (mv[0] + step) not in seen and mv[0] + step >= 0:
+            to_explore.append((mv[0] + step, 1, False))
+        if mv[0] < size and (mv[0] - step) not in seen and mv[0] - step >= 0:
+            to_explore.append((mv[0] - step, -1, False))
+    if not seen:
+        return "empty"
+    best = None
+    for i, s in seen.items():                                  # insertion order: first (or last) maximum
+        if best is None or s > best[1] or (tie_last and s == best[1]):
+            best = (i, s)
+    return best[0], best[1], n
 
 
 # ---- realignment (strkit/call/realign.py) ---------------------------------------------------

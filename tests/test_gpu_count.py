@@ -47,13 +47,19 @@ def test_window_miss_path(gpu_ctx):
 
 
 @pytest.mark.parametrize("kw", [dict(feedback=False), dict(tie_rule=1), dict(max_iters=5), dict(lsr=1, step=2),
-                                dict(lsr=1, step=15, max_iters=50), dict(end_flags=0), dict(end_flags=10)])
+                                dict(lsr=1, step=15, max_iters=50), dict(end_flags=0), dict(end_flags=10),
+                                dict(narrowing=1), dict(narrowing=2, lsr=5), dict(narrowing=3), dict(narrowing=1, lsr=4, step=2, tie_rule=1),
+                                dict(narrowing=3, lsr=5, feedback=False, band=False)])
 def test_search_variants(gpu_ctx, kw):
     rng = np.random.default_rng(22)
     loci = [random_locus(rng, 6, motif_len=(1, 6), cn=(0, 25), flank=(10, 70), alpha=ALPHA_WC) for _ in range(50)]
+    if "narrowing" in kw:   # estimates a few sizes off: the schedules differ only when the search has to walk
+        loci += [random_locus(rng, 8, motif_len=(2, 6), cn=(5, 40), flank=(70, 70), edits=(0, 2)) for _ in range(60)]
     b = LocusBatch.from_reads(loci)
+    if "narrowing" in kw:
+        b.est_cn = np.maximum(0, b.est_cn + rng.integers(-7, 8, size=b.n_reads)).astype(np.int32)
     got, _ = _run(b, gpu_ctx, **dict(kw))
-    okw = dict(max_iters=kw.get("max_iters", 50), lsr=kw.get("lsr", 3), step=kw.get("step", 1),
+    okw = dict(max_iters=kw.get("max_iters", 50), lsr=kw.get("lsr", 3), step=kw.get("step", 1), narrowing=kw.get("narrowing", 0),
                tie_rule=kw.get("tie_rule", 0), flags=kw.get("end_flags", 15), feedback=kw.get("feedback", True))
     _compare(b, got, oracle_count(b, **okw))
 
@@ -338,7 +344,7 @@ def test_unknown_narrowing_schedule_is_rejected(gpu_ctx):
     import ctypes as C
     b = make_config(2, n_loci=3)
     s, keep = batch_struct(b)
-    p = make_params(narrowing=1)
+    p = make_params(narrowing=4)
     outs = [np.zeros(b.n_reads, np.int32) for _ in range(4)]
     rc = _lib.load().strk_count_loci(gpu_ctx.handle, C.byref(s), C.byref(p), *[o.ctypes.data for o in outs], None)
     assert rc == -22 and b"narrowing" in _lib.load().strk_last_error()

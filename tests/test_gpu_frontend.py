@@ -98,14 +98,14 @@ def test_cli_writes_json(gpu_ctx, tmp_path):
 
 
 def test_compare_tool_finds_the_generating_switches(gpu_ctx, tmp_path):
-    """tools/compare_strkit_json.py on a report that plays STRkit's: a report made with tie_rule = last-maximum and a
-    one-sided end-gap mode is reproduced by exactly that combination of the sweep, and the plain diff against the
-    default switches sees the differing reads."""
+    """tools/compare_strkit_json.py on a report that plays STRkit's: a report made with tie_rule = last-maximum, a
+    one-sided end-gap mode and a halving search range is reproduced by that combination of the sweep (16 end-gap modes x 2 tie
+    rules x 4 schedules), and the plain diff against the default switches sees the differing reads."""
     import importlib.util
     import os
     from strkit_amd.frontend.compare import diff_reports
     t = make_dataset(str(tmp_path), n_loci=14, reads_per_locus=8, read_len=1500, seed=21, sub=0.02, indel=0.03, motif_len=(1, 3))
-    theirs = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"], tie_rule=1, end_flags=5)
+    theirs = call_sample(t["paths"]["bam"], t["paths"]["ref"], t["paths"]["loci"], tie_rule=1, end_flags=5, narrowing=2)
     theirs["parameters"]["rc_method"] = "repalign"
     path = str(tmp_path / "strkit.json")
     json.dump(theirs, open(path, "w"))
@@ -119,8 +119,8 @@ def test_compare_tool_finds_the_generating_switches(gpu_ctx, tmp_path):
     out = str(tmp_path / "sweep.json")
     rc = tool.main([path, "--bam", t["paths"]["bam"], "--ref", t["paths"]["ref"], "--loci", t["paths"]["loci"], "--sweep", "--json", out])
     rows = json.load(open(out))
-    assert rc == 0 and len(rows) == 32 and rows[0]["identical"]
-    assert (5, 1) in {(r["end_flags"], r["tie_rule"]) for r in rows if r["identical"]}
+    assert rc == 0 and len(rows) == 128 and rows[0]["identical"]
+    assert (5, 1, 2) in {(r["end_flags"], r["tie_rule"], r["narrowing"]) for r in rows if r["identical"]}
     assert tool.main([path, "--ours", path]) == 0
     ours_path = str(tmp_path / "ours.json")
     json.dump(default, open(ours_path, "w"))

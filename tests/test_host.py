@@ -412,3 +412,61 @@ int main() {
     n_ok, bad, fly_limits = (int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
     assert n_ok > 1_000_000 and bad == 0
     assert fly_limits == 0      # the on-the-fly classes never get a flank or a motif their staged 2 x 256 bytes cannot hold
+
+
+def test_search_replay_with_every_narrowing_schedule_equals_a_plain_python_search(tmp_path):
+    """Host build of strk_search.h::search_replay (the function the kernels and the window-miss path run) against the plain
+    Python loop above on 20 000 random score tables: every schedule of local_search_range (STRK_NARROW_*), both tie rules,
+    steps 1-5, ranges 0-5, small max_iters, starts inside and outside the table (window misses), flat tables (ties)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "search_check.cpp"
+    src.write_text(r"""
+#include <cstdio>
+#include <vector>
+#include "%s/strkit_amd/csrc/strk_search.h"
+struct Seen { std::vector<char> v; bool test(int k) const { return v[k]; } void set(int k) { v[k] = 1; } };
+int main() {
+    int start, step, lsr, max_iters, tie, narrow, lo, n;
+    while (scanf("%%d %%d %%d %%d %%d %%d %%d %%d", &start, &step, &lsr, &max_iters, &tie, &narrow, &lo, &n) == 8) {
+        std::vector<int32_t> sc(n);
+        for (int k = 0; k < n; ++k) scanf("%%d", &sc[k]);
+        Seen seen; seen.v.assign(n, 0);
+        strk::SearchResult r = strk::search_replay(start, step, lsr, max_iters, tie, sc.data(), lo, n, seen, narrow);
+        if (r.miss) printf("miss\n"); else if (r.empty) printf("empty\n"); else printf("%%d %%d %%d\n", r.cn, r.score, r.n_explored);
+    }
+    return 0;
+}
+""" % root)
+    exe = tmp_path / "search_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe), str(src)], check=True)
+    from helpers import py_search
+    rng = np.random.default_rng(20261009)
+    lines, want = [], []
+    for _ in range(20000):
+        lo, n = int(rng.integers(0, 30)), int(rng.integers(1, 48))
+        kind = int(rng.integers(4))
+        peak = lo + int(rng.integers(-3, n + 3))
+        if kind == 0:
+            sc = rng.integers(-50, 400, size=n)
+        elif kind == 1:                                        # one hill, noisy
+            sc = 300 - 7 * np.abs(np.arange(lo, lo + n) - peak) + rng.integers(-6, 7, size=n)
+        elif kind == 2:                                        # plateaus: ties decide
+            sc = 300 - 10 * (np.abs(np.arange(lo, lo + n) - peak) // 3)
+        else:
+            sc = np.full(n, 17)
+        start = lo + int(rng.integers(-4, n + 4))
+        step, lsr = int(rng.integers(1, 6)), int(rng.integers(0, 6))
+        max_iters, tie, narrow = int(rng.choice((1, 3, 7, 20, 50))), int(rng.integers(2)), int(rng.integers(4))
+        lines.append(" ".join(str(int(x)) for x in (start, step, lsr, max_iters, tie, narrow, lo, n, *sc)))
+        want.append(py_search(start, step, lsr, max_iters, tie, narrow, {lo + k: int(sc[k]) for k in range(n)}))
+    out = subprocess.run([str(exe)], input="\n".join(lines) + "\n", check=True, capture_output=True, text=True).stdout.split("\n")
+    seen_kinds = set()
+    for k, (line, w) in enumerate(zip(out, want)):
+        g = line if line in ("miss", "empty") else tuple(int(x) for x in line.split())
+        assert g == w, (k, lines[k][:80], g, w)
+        seen_kinds.add(w if isinstance(w, str) else "found")
+    assert seen_kinds == {"miss", "found"} or seen_kinds == {"miss", "found", "empty"}

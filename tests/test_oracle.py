@@ -318,3 +318,35 @@ def test_simd_scoring_equals_the_scalar_restatement():
                 assert oracle.repeat_count(start, tr, fl, fr, motif) == a
     finally:
         oracle.set_simd(False)
+
+
+def test_narrowing_schedules_of_the_oracle_equal_a_plain_python_search():
+    """strk_o_repeat_count's rule word (tie rule + schedule of local_search_range) against the plain Python loop of
+    tests/helpers.py::py_search over a table of the oracle's own candidate scores: 4 schedules x 2 tie rules x steps and
+    ranges, starts from exact to far off.  (tests/test_host.py holds the product's search_replay against the same loop.)"""
+    from helpers import noisy_tract, py_search, rand_seq
+    rng = np.random.default_rng(20261010)
+    n_diff = 0
+    for _ in range(60):
+        m = int(rng.integers(1, 7))
+        motif = rand_seq(rng, m)
+        cn = int(rng.integers(0, 25))
+        fl, fr = rand_seq(rng, int(rng.integers(5, 40))), rand_seq(rng, int(rng.integers(5, 40)))
+        tr = noisy_tract(rng, motif, cn, int(rng.integers(0, 5)), "ACGT")
+        table = {i: oracle.candidate_score(tr, fl, fr, motif, i) for i in range(0, cn + 12 + 50 * 9 + 10)}   # (as far as 50 steps of 3 + 5 can walk)
+        for _ in range(12):
+            start = max(0, cn + int(rng.integers(-12, 13)))
+            step, lsr = int(rng.integers(1, 4)), int(rng.integers(0, 6))
+            max_iters, tie = int(rng.choice((3, 10, 50))), int(rng.integers(2))
+            res = []
+            for narrow in range(4):
+                want = py_search(start, step, lsr, max_iters, tie, narrow, table)
+                try:
+                    got = oracle.repeat_count(start, tr, fl, fr, motif, max_iters, lsr, step, tie, narrowing=narrow)
+                    got = (got[0][0], got[0][1], got[1])
+                except ValueError:
+                    got = "empty"
+                assert got == want, (motif, tr, start, step, lsr, max_iters, tie, narrow, got, want)
+                res.append(got)
+            n_diff += len(set(res)) > 1
+    assert n_diff > 20          # the schedules are not one and the same on these inputs

@@ -57,14 +57,14 @@ def main(argv=None) -> int:
               respect_ref=tp.get("respect_ref", False), min_read_align_score=tp.get("min_read_align_score", 0.1),
               rc_params=RepeatCountParams("repalign", tp.get("max_rcn_iters", 50), 3, 1))
 
-    def run(end_flags=15, tie_rule=0):
-        return call_sample(bam, ref, a.loci, end_flags=end_flags, tie_rule=tie_rule, **kw)
+    def run(end_flags=15, tie_rule=0, narrowing=0):
+        return call_sample(bam, ref, a.loci, end_flags=end_flags, tie_rule=tie_rule, narrowing=narrowing, **kw)
 
     if a.sweep:
-        rows = sweep(theirs, run)
-        print("end_flags tie_rule  cn_equal  sc_equal  reads_common  only_theirs  only_ours")
+        rows = sweep(theirs, run, narrowings=(0, 1, 2, 3))
+        print("end_flags tie_rule narrowing  cn_equal  sc_equal  reads_common  only_theirs  only_ours")
         for r in rows:
-            print(f"{r['end_flags']:9d} {r['tie_rule']:8d} {r['cn_equal']:9d} {r['sc_equal']:9d} {r['reads_common']:13d} "
+            print(f"{r['end_flags']:9d} {r['tie_rule']:8d} {r['narrowing']:9d} {r['cn_equal']:9d} {r['sc_equal']:9d} {r['reads_common']:13d} "
                   f"{r['reads_only_theirs']:12d} {r['reads_only_ours']:10d}{'   <- identical' if r['identical'] else ''}")
         if a.json:
             json.dump(rows, open(a.json, "w"), indent=1)

@@ -11,7 +11,8 @@ worker processes that are forked BEFORE this process touches the GPU; the GPU si
   shape   — short HiFi-like loci; noisy (ONT-like) loci; long expansions (wide band classes, the long kernel); ragged
             flanks (0..80 bases) and empty tracts; IUPAC motifs; reads with X / N wildcards; lower-case stretches;
             start estimates from exact to wildly off (0, three times the size);
-  search  — max_iters, local_search_range, step_size, tie rule, the four free-end flags, in-locus feedback on / off;
+  search  — max_iters, local_search_range, step_size, tie rule, the four free-end flags, in-locus feedback on / off, the
+            schedule of local_search_range (STRK_NARROW_*);
   library — adaptive or pinned candidate window, dedupe on / off, banded first pass on / off.
 Exit code 1 on the first mismatch (its round, read and the two answers are printed and written to --out).
 """
@@ -119,7 +120,7 @@ def make_round(seed: int, i: int):
         step=int(rng.choice((1, 1, 1, 2, 3, 5))), tie_rule=int(rng.integers(2)),
         flags=15 if rng.random() < 0.6 else int(rng.integers(16)), feedback=bool(rng.random() < 0.7),
         window=0 if rng.random() < 0.6 else int(rng.integers(4, 16)), dedupe=bool(rng.random() < 0.8),
-        band=bool(rng.random() < 0.8), shape=shape)
+        band=bool(rng.random() < 0.8), narrowing=0 if rng.random() < 0.6 else int(rng.integers(1, 4)), shape=shape)
     # bound the ORACLE's time per round to seconds of one core: about 9 G cells/s in its AVX2 pass, 0.5 G in the scalar code that
     # the non-default end flags and the IUPAC motifs take; a wild estimate runs the search to max_iters
     budget = 1e10 if p["flags"] == 15 and shape != "iupac" else 6e8
@@ -144,7 +145,7 @@ def oracle_round(args):
     b, p = make_round(seed, i)
     t0 = time.perf_counter()
     try:
-        exp = oracle_count(b, p["max_iters"], p["lsr"], p["step"], p["tie_rule"], p["flags"], p["feedback"])
+        exp = oracle_count(b, p["max_iters"], p["lsr"], p["step"], p["tie_rule"], p["flags"], p["feedback"], p["narrowing"])
     except ValueError as e:                                  # max() of nothing: the library answers STRK_E_EMPTY
         return i, None, str(e), time.perf_counter() - t0
     return i, exp, None, time.perf_counter() - t0
@@ -197,7 +198,7 @@ def main() -> int:
         ctx = _lib.Context(0) if own else shared
         rc_params = RepeatCountParams("repalign", p["max_iters"], p["lsr"], p["step"])
         kw = dict(feedback=p["feedback"], window=p["window"], tie_rule=p["tie_rule"], end_flags=p["flags"], dedupe=p["dedupe"],
-                  band=p["band"])
+                  band=p["band"], narrowing=p["narrowing"])
         got = {}
         t_call = time.perf_counter()
         try:
@@ -252,7 +253,7 @@ def main() -> int:
         if bad:
             break
         # the scalar drop-in (default switches) on the first read of a few loci — what feedback cannot have touched
-        if p["flags"] == 15 and p["tie_rule"] == 0 and b.n_reads:
+        if p["flags"] == 15 and p["tie_rule"] == 0 and p["narrowing"] == 0 and b.n_reads:
             from strkit_amd.repeats import get_repeat_count
             for l in range(min(3, b.n_loci)):
                 r = int(b.read_off[l])
