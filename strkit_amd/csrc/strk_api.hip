@@ -132,7 +132,7 @@ struct DevBuf {
 struct strk_ctx {
     int device = 0;
     // workspace
-    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, band_recs, band_recs_w, counters, scratch, state_i32, state_f64, spec, rhash, rep, exact;
+    DevBuf read_locus, win_lo, win_n, tab_off, table, cls_list, band_recs, band_recs_w, long_list, counters, scratch, state_i32, state_f64, spec, rhash, rep, exact;
     DevBuf win_lo2, win_n2, tab_off2, table2, items;
     DevBuf sc_dev;                  // strk_repeat_count's fast path: one read's arrays in one device buffer ...
     uint8_t* sc_host = nullptr;     // ... their pinned host image (one copy up) and the pinned result (one copy down)
@@ -413,9 +413,19 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
         else hipLaunchKernelGGL(k_dp_all, dim3(blocks), dim3(256), 0, st, a);
     }
     if (time_dp) (void)hipEventRecord(c->ev[kEvExact], st);
+    KArgs al = a;
+    if (!force_generic && !a.ref_mode) {
+        // longest first when there are more long items than resident waves (k_sort_long) — by the previous call's count, or
+        // the item count the host knows (window-miss rounds, explicit tables); a call without them does not pay the launch
+        const bool many_long = mode == 0 ? (!hist || c->hist_long > kLongWaves) : a.list_stride > kLongWaves;   // (no history: one block finds out)
+        if (many_long && !c->long_list.ensure((size_t)std::max(1, a.list_stride) * 2 * 4)) {
+            hipLaunchKernelGGL(k_sort_long, dim3(1), dim3(1024), 0, st, a, c->long_list.as<int32_t>());
+            al.long_sorted = c->long_list.as<int32_t>();
+        }
+    }
     if (!force_generic && !a.ref_mode)   // (a window-miss round or an explicit table: never more blocks than items)
         hipLaunchKernelGGL(k_dp_long, dim3(mode == 0 ? predicted_blocks(c->hist_long, kLongBlocks) : std::max(1, std::min(kLongBlocks, a.list_stride))),
-                           dim3(256), 0, st, a);
+                           dim3(256), 0, st, al);
     if (time_dp) (void)hipEventRecord(c->ev[kEvLong], st);
     hipLaunchKernelGGL(k_dp_generic, dim3(1024), dim3(256), 0, st, a);   // one wave per (item, candidate): 4 096 waves
     if (time_dp) (void)hipEventRecord(c->ev[kEvGeneric], st);
@@ -972,7 +982,7 @@ void strk_destroy(strk_ctx* c) {
                       &c->items, &c->in_seqs, &c->in_seq_off, &c->in_nfl, &c->in_ntr, &c->in_nfr, &c->in_est,
                       &c->in_read_off, &c->in_motifs, &c->in_motif_off, &c->out_cn, &c->out_score, &c->out_n,
                       &c->out_start, &c->rl_s1, &c->rl_s2, &c->rl_pairs, &c->rl_trace, &c->rl_edge, &c->rl_out, &c->rl_cigar,
-                      &c->rl_queue, &c->band_recs_w, &c->sc_dev};
+                      &c->rl_queue, &c->band_recs_w, &c->sc_dev, &c->long_list};
     for (DevBuf* b : bufs) b->release();
     {
         std::lock_guard<std::mutex> lk(g_band_chain_mu);

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_dp_long(KArgs a) {
     int* const colB = reinterpret_cast<int*>(Lw + LongLayout::OFF_COLB);
     const bool dbBeg = a.end_flags & 1, dbEnd = a.end_flags & 2, cBeg = a.end_flags & 4, cEnd = a.end_flags & 8;
     const int count = min(a.counters[kCntClass0 + kLongClass], a.list_stride);
-    const int32_t* list = a.cls_list + (size_t)kLongClass * a.list_stride * 2;
+    const int32_t* list = a.long_sorted ? a.long_sorted : a.cls_list + (size_t)kLongClass * a.list_stride * 2;
 
     for (;;) {
         __builtin_amdgcn_wave_barrier();   // the wave enters every iteration whole (see k_realign_dp)

@@ -79,6 +79,7 @@ struct KArgs {
     int32_t* cls_list;    // [kNumLists * list_stride * 2]  (read, chunk start) pairs
     int4* band_recs;      // [kNumBandClasses * list_stride * 3]  everything a band item needs, written by k_plan:
                           //   (read, locus, nfl, ntr) (nfr, m, lo, n) (seq_off lo, seq_off hi, motif_off, est_cn)
+    const int32_t* long_sorted;   // k_dp_long's item list in k_sort_long's order (longest first), or NULL: the class list as it was filled
     int4* band_recs_w;    // the records k_dp_band_wide reads: band_recs, or k_sort_wide's copy of the four wide classes, longest first
     int32_t* wide_hist;   // [2][kNumWideLists][256] items of the wide band classes by prefix rows / 64 (k_plan), then the cursors
                           //    k_sort_wide hands positions out with (zeroed with the counters)
@@ -481,6 +482,57 @@ __global__ void __launch_bounds__(256) k_sort_wide(KArgs a, int4* out) {
         const int pos = s_start[s][b] + atomicAdd(&a.wide_hist[(kNumWideLists + s) * 256 + b], 1);
         int4* o = out + ((size_t)cls * a.list_stride + pos) * 3;
         o[0] = q0; o[1] = q1; o[2] = q2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Longest first for k_dp_long too.  One read per wave and 2 048 resident waves: a call with more long items than that (config
+// 5's shape when no certificate holds — noisy reads) is as long as whatever its last waves pick up, and the items differ by a
+// factor of a thousand in cells (|db| x rows, 50-2 000 copies).  Measured by itself (tools/prof_long.sh, 13 560 items): the
+// waves were resident for 65 % of the launch.  The list is filled by k_plan, by the band kernels' fall-backs and by k_replay,
+// so the order is made here, right in front of the kernel: one block, a histogram of cost (column tiles x steps, in 1 024
+// buckets), positions from a suffix sum, a scatter.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_sort_long(KArgs a, int32_t* out) {
+    __shared__ int s_hist[1024], s_start[1024];
+    const int count = min(a.counters[kCntClass0 + kLongClass], a.list_stride);
+    if (count <= 0) return;
+    const int32_t* list = a.cls_list + (size_t)kLongClass * a.list_stride * 2;
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    auto bucket_of = [&](int r, int k0) {
+        const int l = a.read_locus[r];
+        const int m = a.motif_off[l + 1] - a.motif_off[l];
+        const long long ndb = (long long)a.nfl[r] + a.ntr[r] + a.nfr[r];
+        const long long rows = (long long)a.nfl[r] + (long long)(a.win_lo[r] + k0 + min(kTableMax, a.win_n[r] - k0) - 1) * m;
+        const long long cost = ((ndb + kLongTile) / kLongTile) * (rows + 64);
+        return 1023 - (int)min(1023ll, cost >> 9);        // bucket 0 = the longest
+    };
+    for (int i = threadIdx.x; i < count; i += 1024) atomicAdd(&s_hist[bucket_of(list[2 * i], list[2 * i + 1])], 1);
+    __syncthreads();
+    {   // exclusive prefix sum over the 1 024 buckets: per-wave scan, then the 16 wave totals
+        __shared__ int s_wave[16];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int v = s_hist[threadIdx.x];
+        int incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) s_wave[w] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < w; ++k) base += s_wave[k];
+        s_start[threadIdx.x] = base + incl - v;
+        s_hist[threadIdx.x] = 0;                            // re-used as the buckets' cursors
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < count; i += 1024) {
+        const int r = list[2 * i], k0 = list[2 * i + 1];
+        const int b = bucket_of(r, k0);
+        const int pos = s_start[b] + atomicAdd(&s_hist[b], 1);
+        out[2 * pos] = r;
+        out[2 * pos + 1] = k0;
     }
 }
 
