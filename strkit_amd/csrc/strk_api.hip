@@ -957,6 +957,9 @@ int strk_init(int device, strk_ctx** out) {
     c->device = device;
     c->long_slot_ints = kLongSlotInts;
     c->generic_ints = kGenericPoolInts;
+    // testing aids: a context that starts with small scratch parts, so that a small input walks the grow-and-run-again path
+    if (const char* e = getenv("STRKIT_AMD_GENERIC_POOL_INTS")) c->generic_ints = (size_t)std::max(1l, atol(e));
+    if (const char* e = getenv("STRKIT_AMD_LONG_SLOT_INTS")) c->long_slot_ints = (size_t)std::max(1l, atol(e));
     strk::ScoreTables t;
     strk::build_score_tables(&t);
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(strk::c_mat), t.mat, sizeof t.mat);

@@ -170,12 +170,16 @@ def test_reads_with_more_than_eight_symbol_classes_are_searched_on_the_generic_t
             _compare(b, got, oracle_count(b, 7, 1, 1, 0, 15, feedback))
 
 
-def test_generic_pool_grows_for_a_batch_of_flankless_reads(fresh_ctx):
-    """Reads without a left flank go to the generic kernel, whose H rows live in a pool of 16 Mi ints: 250 loci x 24 such reads
-    of ~750 bases ask for more than that (one row per thread, 65 536 threads).  The call must grow the pool and run again
-    instead of failing with STRK_E_NOMEM — found by tools/fuzz_parity.py (seed 2), where a few hundred ragged loci failed a
-    whole call.  The first and the last loci are checked against the oracle; the score-table entry point takes the same way."""
+def test_generic_pool_grows_for_a_batch_of_flankless_reads(monkeypatch):
+    """Reads without a left flank go to the generic kernel, whose H rows live in a pool that a context sizes once.  A call
+    that asks for more must grow the pool and run again instead of failing with STRK_E_NOMEM — found by tools/fuzz_parity.py
+    (seed 2), where a few hundred ragged loci failed a whole call (one row per thread then; one per wave now, so the contexts
+    of this test start with a pool of 64 Ki ints: about eighty rows).  The first and the last loci are checked against the
+    oracle; the window-miss rounds and the score-table entry point take the same way."""
+    from strkit_amd import _lib
     from strkit_amd.batch import score_table
+    monkeypatch.setenv("STRKIT_AMD_GENERIC_POOL_INTS", str(64 << 10))
+    fresh_ctx = _lib.Context(0)
     rng = np.random.default_rng(20261006)
     loci = []
     for _ in range(250):
@@ -201,7 +205,6 @@ def test_generic_pool_grows_for_a_batch_of_flankless_reads(fresh_ctx):
         loci.append((motif, [("", motif * cn, fr), ("", motif * (cn + 1), fr)]))
         est.append([3 * cn + 1, cn])
     bm = LocusBatch.from_reads(loci, est)
-    from strkit_amd import _lib
     ctx3 = _lib.Context(0)
     try:
         gotm, stm = _run(bm, ctx3, dedupe=False, step=5, lsr=2)
@@ -226,6 +229,7 @@ def test_generic_pool_grows_for_a_batch_of_flankless_reads(fresh_ctx):
             assert tab[r].tolist() == exp
     finally:
         ctx2.close()
+        fresh_ctx.close()
 
 
 def test_long_kernel_slot_grows_for_a_start_far_above_the_tract(fresh_ctx):
