@@ -44,7 +44,9 @@ extern "C" {
 
 #define STRK_OK 0
 #define STRK_E_INVALID (-22) /* bad argument (EINVAL) */
-#define STRK_E_NOMEM (-12)   /* device or host allocation failed (ENOMEM) */
+#define STRK_E_NOMEM (-12)   /* device or host allocation failed (ENOMEM); also: an input beyond what the scratch parts may grow
+                                to (a window of more than 2^20 candidate rows, 32 GiB of generic-kernel rows) — strk_last_error()
+                                says which.  Scratch that is merely too small for a call grows and the call runs again. */
 #define STRK_E_DEVICE (-5)   /* HIP runtime / kernel failure (EIO) */
 #define STRK_E_NODEV (-19)   /* no usable gfx950 device (ENODEV) */
 #define STRK_E_EMPTY (-61)   /* nothing could be scored (Python's max() of an empty dict) */
