@@ -311,15 +311,14 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
                      hipStream_t st, bool time_dp, const ReplayArgs* pre_replay = nullptr) {
     // Longest-first order of the wide band classes (k_sort_wide) pays when their chunks are few against the ~2 000 resident waves —
     // the launch then lasts as long as its longest chunk and whatever was started late (BASELINE config 5 at one GPU's share:
-    // 6 400 chunks, k_dp_band_wide 3.77 -> 3.38 ms) — and costs its census (k_plan) and a small kernel when they are many
-    // (config 4's shard, 16 000 chunks: +0.1 ms for nothing).  Decided by the previous call's queue; a first call sorts.
+    // 6 400 chunks, k_dp_band_wide 3.77 -> 3.38 ms).  Two small kernels (strk_kernels.h: k_sort_wide_hist, k_sort_wide); run when
+    // the previous call had at most 8 192 wide chunks (a first call sorts).  With more — config 4's shard: 16 000 — the order
+    // still shortens k_dp_band_wide (2.03 -> 1.80 ms with ONE call on the device, sort included), but with two calls in flight the
+    // two extra launches between the band kernels moved the calls into the pattern in which their band passes co-run: the
+    // default bench gave 92.8 M reads/s twice where the unsorted queue gives 103-111 (profiles/r04_sort_wide_always_experiment.txt).
     const bool hist0 = mode == 0 && c->hist_valid && c->hist_band_mode == a.band_mode;
     const bool sort_wide = a.band_mode && mode == 0 && !force_generic && (!hist0 || (c->hist_wide_chunks > 0 && c->hist_wide_chunks <= 8192));
-    {
-        KArgs ap = a;
-        if (!sort_wide) ap.wide_hist = nullptr;
-        hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, ap, mode, d_items, n_items, force_generic);
-    }
+    hipLaunchKernelGGL(k_plan, dim3((n_items + 255) / 256), dim3(256), 0, st, a, mode, d_items, n_items, force_generic);
     static const int tune = getenv("STRKIT_AMD_DP_BLOCKS") ? atoi(getenv("STRKIT_AMD_DP_BLOCKS")) : 0;   // tuning aid
     // A call that shares the device with other calls in flight takes fifteen sixteenths of the CU slots per kernel: the free
     // slots are what lets the LDS-holding tail kernels of one call (k_dp_band_wide, k_dp_all, k_dp_long) start while another
@@ -394,7 +393,8 @@ void enqueue_scoring(strk_ctx* c, const KArgs& a, int mode, const int32_t* d_ite
     if (band) {   // long windows
         KArgs aw = a;
         if (sort_wide) {
-            hipLaunchKernelGGL(k_sort_wide, dim3(64), dim3(256), 0, st, a, c->band_recs_w.as<int4>());
+            hipLaunchKernelGGL(k_sort_wide_hist, dim3(kSortWideBlocks, kNumWideLists), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_sort_wide, dim3(kSortWideBlocks, kNumWideLists), dim3(256), 0, st, a, c->band_recs_w.as<int4>());
             aw.band_recs_w = c->band_recs_w.as<int4>();
         }
         const int wide_full = std::max(1, std::min(tune > 0 ? tune : std::max(1, 256 * kBandBlocksPerCU * s16_wide / 16 - (s16_wide == 16 ? spare : 0)), (a.list_stride + 3) / 4));

@@ -81,7 +81,7 @@ struct KArgs {
                           //   (read, locus, nfl, ntr) (nfr, m, lo, n) (seq_off lo, seq_off hi, motif_off, est_cn)
     const int32_t* long_sorted;   // k_dp_long's item list in k_sort_long's order (longest first), or NULL: the class list as it was filled
     int4* band_recs_w;    // the records k_dp_band_wide reads: band_recs, or k_sort_wide's copy of the four wide classes, longest first
-    int32_t* wide_hist;   // [2][kNumWideLists][256] items of the wide band classes by prefix rows / 64 (k_plan), then the cursors
+    int32_t* wide_hist;   // [2][kNumWideLists][256] items of the wide band classes by prefix rows / 64 (k_sort_wide_hist), then the cursors
                           //    k_sort_wide hands positions out with (zeroed with the counters)
     int32_t* counters;    // see Counter enum
     unsigned long long* cells;  // DP cells executed; cells[2] / cells[3]: algorithmic bytes (|window| + 16 per read) of the
@@ -390,8 +390,6 @@ __global__ void __launch_bounds__(256) k_plan(KArgs a, int mode, const int32_t* 
                 rec[0] = make_int4(r, l, nfl, ntr);
                 rec[1] = make_int4(nfr, m, lo, n);
                 rec[2] = make_int4((int)(so & 0xffffffffll), (int)(so >> 32), a.motif_off[l], a.est_cn[r]);
-                if (a.wide_hist && band_class_wide_kernel(band_list - kBandClass0))   // census for the longest-first order (k_sort_wide)
-                    atomicAdd(&a.wide_hist[wide_slot(band_list - kBandClass0) * 256 + wide_bucket(nfl + (lo + n - 1) * m)], 1);
             }
         } else {
             atomicOr(&a.counters[kCntError], kErrList);
@@ -450,36 +448,60 @@ __global__ void __launch_bounds__(64) k_scalar_plan(KArgs a, int n_counter_ints)
 // have nothing left (BASELINE config 5 at one GPU's share: 6 400 chunks for 1 900 waves, class by class but in arrival order
 // inside a class), and two reads that share a wave in lock step should be of one length.
 // ---------------------------------------------------------------------------------------------
+// Two kernels of kSortWideBlocks blocks per class (round 4, last hours).  The first form took the histogram from k_plan — one
+// global atomic per wide item — which cost config 4's shard (16 000 wide chunks) what the order gave back, so only small queues
+// were sorted; a single block per class with the histogram in LDS took a millisecond for 32 000 records.  Now every block
+// counts its slice in LDS and adds its 256 counts to the class's histogram (k_sort_wide_hist); then (k_sort_wide) it counts
+// again, turns the class histogram into bucket starts, reserves its range per bucket with one atomic on the bucket's cursor
+// and scatters its records by LDS-local offsets.  Global atomics: two per block and occupied bucket.
+constexpr int kSortWideBlocks = 16;
+__device__ __forceinline__ int wide_rec_bucket(const int4* recs, int idx) {
+    const int4 q0 = recs[(size_t)idx * 3], q1 = recs[(size_t)idx * 3 + 1];
+    return 255 - wide_bucket(q0.z + (q1.z + q1.w - 1) * q1.y);   // nfl + (lo + n - 1) * m; bucket 0 = the longest
+}
+__global__ void __launch_bounds__(256) k_sort_wide_hist(KArgs a) {
+    __shared__ int s_hist[256];
+    const int s = blockIdx.y, cls = wide_slot_class(s);
+    const int count = min(a.counters[kCntClass0 + kBandClass0 + cls], a.list_stride);
+    if (count <= 0) return;
+    const int4* recs = a.band_recs + (size_t)cls * a.list_stride * 3;
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += kSortWideBlocks * 256) atomicAdd(&s_hist[wide_rec_bucket(recs, i)], 1);
+    __syncthreads();
+    if (s_hist[threadIdx.x]) atomicAdd(&a.wide_hist[s * 256 + threadIdx.x], s_hist[threadIdx.x]);
+}
 __global__ void __launch_bounds__(256) k_sort_wide(KArgs a, int4* out) {
-    __shared__ int s_start[kNumWideLists][256];   // first position of each bucket in the descending order
-    __shared__ int s_cnt[kNumWideLists];
-    int total = 0;
-    for (int s = 0; s < kNumWideLists; ++s) total += min(a.counters[kCntClass0 + kBandClass0 + wide_slot_class(s)], a.list_stride);
-    if (total == 0) return;
-    {   // 1 024 = 4 lists x 256 buckets: thread t scans list t / 64's buckets (t % 64) * 4 .. + 3 after a per-list suffix sum
-        const int s = threadIdx.x >> 6, q = threadIdx.x & 63;
-        const int* h = a.wide_hist + s * 256;
-        int mine[4], sum = 0;
-        for (int k = 0; k < 4; ++k) { mine[k] = h[255 - (q * 4 + k)]; sum += mine[k]; }   // descending: bucket 255 first
-        // exclusive scan of `sum` over the 64 lanes of this wave (= this list)
-        int incl = sum;
+    __shared__ int s_cnt[256], s_base[256], s_wave[4];
+    const int s = blockIdx.y, cls = wide_slot_class(s);
+    const int count = min(a.counters[kCntClass0 + kBandClass0 + cls], a.list_stride);
+    if (count <= 0) return;
+    const int4* recs = a.band_recs + (size_t)cls * a.list_stride * 3;
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += kSortWideBlocks * 256) atomicAdd(&s_cnt[wide_rec_bucket(recs, i)], 1);
+    __syncthreads();
+    {   // where bucket t of the class begins (exclusive prefix sum of the class histogram), plus this block's reserved offset in it
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int v = a.wide_hist[s * 256 + threadIdx.x];
+        int incl = v;
         for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (q >= o) incl += v;
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
         }
-        int pos = incl - sum;
-        for (int k = 0; k < 4; ++k) { s_start[s][255 - (q * 4 + k)] = pos; pos += mine[k]; }
-        if (q == 0) s_cnt[s] = min(a.counters[kCntClass0 + kBandClass0 + wide_slot_class(s)], a.list_stride);
+        if (lane == 63) s_wave[w] = incl;
+        __syncthreads();
+        int base = incl - v;
+        for (int k = 0; k < w; ++k) base += s_wave[k];
+        const int mine = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = mine ? base + atomicAdd(&a.wide_hist[(kNumWideLists + s) * 256 + threadIdx.x], mine) : 0;
+        s_cnt[threadIdx.x] = 0;   // re-used as this block's cursor inside its range
     }
     __syncthreads();
-    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
-        int s = 0, idx = g;
-        while (idx >= s_cnt[s]) { idx -= s_cnt[s]; ++s; }
-        const int cls = wide_slot_class(s);
-        const int4* rec = a.band_recs + ((size_t)cls * a.list_stride + idx) * 3;
-        const int4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-        const int b = wide_bucket(q0.z + (q1.z + q1.w - 1) * q1.y);
-        const int pos = s_start[s][b] + atomicAdd(&a.wide_hist[(kNumWideLists + s) * 256 + b], 1);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += kSortWideBlocks * 256) {
+        const int4 q0 = recs[(size_t)i * 3], q1 = recs[(size_t)i * 3 + 1], q2 = recs[(size_t)i * 3 + 2];
+        const int b = 255 - wide_bucket(q0.z + (q1.z + q1.w - 1) * q1.y);
+        const int pos = s_base[b] + atomicAdd(&s_cnt[b], 1);
         int4* o = out + ((size_t)cls * a.list_stride + pos) * 3;
         o[0] = q0; o[1] = q1; o[2] = q2;
     }
