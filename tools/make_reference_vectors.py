@@ -21,7 +21,7 @@ motifs, start estimates):
 
 and writes ONE JSON file of inputs and outputs.  Commit that file: `tests/test_reference_vectors.py` then checks the CPU
 oracle against it (`-m "not gpu"`) and the HIP library against it (`-m gpu`), and names, if the defaults do not reproduce
-it, which combination of the open switches (end-gap flags x tie rule) does.  Without the file those
+it, which combinations of the open switches (end-gap flags x tie rule x search-range schedule) do.  Without the file those
 tests skip; parity stays "unpinned" until it exists.  Nothing of STRkit's source is read or copied by this script: it only
 imports the installed package and records what its functions return.
 """
