@@ -405,6 +405,29 @@ def test_report_diff_logic():
     assert same["identical"] and same["diffs"] == [] and same["sc_compared"] == 2
 
 
+def test_report_sweep_orders_the_switch_combinations():
+    """strkit_amd/frontend/compare.py::sweep over end-gap mode x tie rule x search-range schedule with a made-up `run`: the
+    generating combination comes first and is the only identical one; without `narrowings` the callback keeps its two-argument
+    form (tools written against the round-3 signature)."""
+    from strkit_amd.frontend.compare import sweep
+
+    def report(ef, tie, nw=0):
+        cn = 10 + (ef == 5) + 2 * (tie == 1) + 4 * (nw == 2)
+        return {"results": [{"locus_index": 1, "contig": "chr1", "start": 10, "end": 40, "motif": "CAG", "ref_cn": 10,
+                             "reads": {"r1": {"s": "+", "sc": 1.5 + 0.1 * ef, "cn": cn}, "r2": {"s": "-", "sc": 2.0, "cn": 10 + (tie == 1)}}}]}
+    theirs = report(5, 1, 2)
+    rows = sweep(theirs, report, end_flags=(15, 5), tie_rules=(0, 1), narrowings=(0, 1, 2, 3))
+    assert len(rows) == 16 and rows[0]["identical"] and (rows[0]["end_flags"], rows[0]["tie_rule"], rows[0]["narrowing"]) == (5, 1, 2)
+    assert sum(r["identical"] for r in rows) == 1 and rows[0]["cn_equal"] == 2 and rows[-1]["cn_equal"] < 2
+    calls = []
+
+    def two_args(ef, tie):
+        calls.append((ef, tie))
+        return report(ef, tie)
+    rows2 = sweep(report(15, 1), two_args, end_flags=(15, 5))
+    assert len(rows2) == 4 and len(calls) == 4 and rows2[0]["identical"] and rows2[0]["narrowing"] == 0
+
+
 def test_indexed_bam_regions_equal_the_whole_file(tmp_path):
     """Block-wise access through the .bai linear index (IndexedBam.region: virtual offset -> strk_bgzf_inflate_range ->
     strk_bam_scan_piece) returns, for every block of loci, the records the whole-file reader finds."""
